@@ -1,0 +1,165 @@
+/* vdb_index.h — C-ABI of the MI355X-native HNSW / brute-force k-NN path.
+ *
+ * This is the drop-in boundary for ONE hot path of cheeriosok/VectorDB: the k-NN query of
+ * src/hnsw/hnsw_scratch (greedy upper-layer descent + ef-bounded layer-0 beam search) and
+ * the exact brute-force k-NN beside it.  Each entry point names the reference interface
+ * it stands in for (paths relative to the reference's src/hnsw/hnsw_scratch/).
+ * The reference surface is C++ (exceptions, std::priority_queue results); across this ABI
+ * everything is plain pointers and sizes, every function returns a status code
+ * (0 = VDB_OK) and vdb_last_error() gives the thread-local message that the C++ wrapper
+ * (vectordb_amd/cpp/vdb_hnsw.hpp) re-throws as std::runtime_error, as the reference does.
+ *
+ * Host-side index state keeps the reference's byte layout (hnsw_core.hpp:45-75, :148-152)
+ * so saveIndex/loadIndex files are interchangeable; vdb_index_to_device repacks it into
+ * the HBM layout described in DESIGN.md.  Search entry points run hand-written gfx950
+ * kernels only: there is no CPU fallback, and they fail with VDB_ERR_NO_DEVICE when the
+ * index has not been uploaded or no GPU is present.
+ */
+#ifndef VDB_INDEX_H
+#define VDB_INDEX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vdb_index vdb_index;           /* HierarchicalNSW<float>, hnsw_core.hpp:21 */
+typedef struct vdb_bruteforce vdb_bruteforce; /* BruteforceSearch<float>, bruteforce.hpp:14 */
+
+enum vdb_metric {
+    VDB_L2 = 0, /* L2Sqr<float>, space_l2.hpp:1-14 */
+    VDB_IP = 1  /* InnerProductDistance<float> = 1 - <a,b>, space_ip.hpp:13-18 */
+};
+
+enum vdb_status {
+    VDB_OK = 0,
+    VDB_ERR_INVALID = 1,     /* bad argument */
+    VDB_ERR_RUNTIME = 2,     /* what the reference reports as std::runtime_error */
+    VDB_ERR_NO_DEVICE = 3,   /* no GPU / index not on device / HIP call failed */
+    VDB_ERR_UNSUPPORTED = 4  /* valid in the reference, not on the device path yet */
+};
+
+/* Order in which a distance is summed (DESIGN.md "Numerics").
+ * VDB_SUM_TREE64 is what the kernels compute and the default for building;
+ * VDB_SUM_SEQ is the reference's strictly sequential fp32 loop (host build only). */
+enum vdb_sum_order { VDB_SUM_SEQ = 0, VDB_SUM_TREE64 = 1 };
+
+/* Precision of the brute-force distance engine. */
+enum vdb_bf_precision {
+    VDB_BF_FP32 = 0,       /* f32 MFMA candidate pass + exact f32 re-rank: ids/dists match the CPU path */
+    VDB_BF_BF16 = 1,       /* bf16 MFMA, f32 accumulate, no re-rank: distances are bf16-grade */
+    VDB_BF_BF16_RERANK = 2 /* bf16 MFMA candidate pass (wider margin) + exact f32 re-rank */
+};
+
+const char* vdb_last_error(void);
+/* Number of visible HIP devices (0 when none; never fails). */
+int vdb_device_count(void);
+
+/* ---- HierarchicalNSW<float> ------------------------------------------------------- */
+
+/* ctor HierarchicalNSW(space, capacity, M=16, efConstruction=200, random_seed=100),
+ * hnsw_core.hpp:118-179; `metric`+`dim` replace the SpaceInterface argument
+ * (hnswlib.hpp:54-61, space_l2.hpp:16-37, space_ip.hpp:20-41). */
+int vdb_index_create(vdb_index** out, int metric, size_t dim, size_t capacity, size_t M,
+                     size_t ef_construction, size_t random_seed);
+/* load ctor / loadIndex, hnsw_core.hpp:110-116, :581-682 (reference byte format). */
+int vdb_index_load(vdb_index** out, const char* path, int metric, size_t dim, size_t capacity);
+/* saveIndex, hnsw_core.hpp:551-579. */
+int vdb_index_save(const vdb_index* idx, const char* path);
+/* ~HierarchicalNSW / clear(), hnsw_core.hpp:181-199 (also frees the device copy). */
+void vdb_index_free(vdb_index* idx);
+
+/* addPoint(datapoint, label), hnsw_core.hpp:804-842 -> :994-1104.  Host build with the
+ * reference's semantics (same graph as the reference algorithm for the same insertion
+ * order, seed and summation order).  `level` < 0 draws the level (hnsw_core.hpp:240-244). */
+int vdb_index_add(vdb_index* idx, const float* vec, uint64_t label, int level);
+/* n addPoint calls; labels NULL = 0..n-1 continuing from the current count.  n_threads > 1
+ * inserts concurrently as the reference allows (label stripes, per-node link locks,
+ * global lock: hnsw_core.hpp:77-84); the link order is then not reproducible. */
+int vdb_index_add_batch(vdb_index* idx, const float* vecs, const uint64_t* labels, size_t n, int n_threads);
+/* Summation order used by host-side build distances (default VDB_SUM_TREE64). */
+int vdb_index_set_build_sum_order(vdb_index* idx, int order);
+
+/* setefSearch, hnsw_core.hpp:207-209 (default 10, :143/:655). */
+int vdb_index_set_ef(vdb_index* idx, size_t ef);
+/* markDelete / unmarkDelete, hnsw_core.hpp:709-782. */
+int vdb_index_mark_delete(vdb_index* idx, uint64_t label);
+int vdb_index_unmark_delete(vdb_index* idx, uint64_t label);
+/* resizeIndex, hnsw_core.hpp:500-522. */
+int vdb_index_resize(vdb_index* idx, size_t new_capacity);
+/* checkIntegrity, hnsw_core.hpp:1216-1245: 0 ok, else 1 id out of range, 2 self link,
+ * 3 duplicate link, 4 node without inbound link. */
+int vdb_index_check_integrity(const vdb_index* idx, int* min_inbound, int* max_inbound);
+
+/* getCapacity / getElementCount / getDeletedCount (hnsw_core.hpp:246-256) and the public
+ * fields the reference exposes (:28-40). */
+size_t vdb_index_capacity(const vdb_index* idx);
+size_t vdb_index_count(const vdb_index* idx);
+size_t vdb_index_deleted_count(const vdb_index* idx);
+size_t vdb_index_dim(const vdb_index* idx);
+size_t vdb_index_M(const vdb_index* idx);
+size_t vdb_index_ef(const vdb_index* idx);
+int vdb_index_max_level(const vdb_index* idx);
+uint32_t vdb_index_entry(const vdb_index* idx);
+int vdb_index_level_of(const vdb_index* idx, uint32_t internal_id);
+/* One node's neighbour list on one level, in stored order (get_neighbors_at_level,
+ * hnsw_core.hpp:259-273); returns the count or -1. */
+int vdb_index_links(const vdb_index* idx, uint32_t internal_id, int level, uint32_t* out, int cap);
+
+/* Repack the host graph into the HBM layout and upload it to `device` (no reference
+ * counterpart: the reference has no device).  Must be called again after add/delete. */
+int vdb_index_to_device(vdb_index* idx, int device);
+/* Bytes the device copy occupies (0 if not uploaded). */
+size_t vdb_index_device_bytes(const vdb_index* idx);
+
+/* SearchKNNCloserFirst over a batch: hnswlib.hpp:87-99 on top of searchKnn,
+ * hnsw_core.hpp:1107-1159 (+ the undefined searchBaseLayerST it calls, :1143-1147).
+ * One wavefront per query.  ef = max(efSearch, k) as :1144.
+ *   d_queries  [nq * dim] f32, DEVICE memory, row-major
+ *   d_out_dist [nq * k]   f32, DEVICE, ascending; rows short of k padded with +inf
+ *   d_out_label[nq * k]   u64, DEVICE; padding = UINT64_MAX
+ *   d_out_stats nullable  [nq * 4] u32, DEVICE: {ndis, nhops layer 0, nhops upper, found}
+ *                         (the reference's metric_distance_computations_/metric_hops_,
+ *                          hnsw_core.hpp:95-96, :1122-1123, per query)
+ *   stream     hipStream_t (NULL = default stream); the call is asynchronous.
+ * Filters and deleted elements (the non-bare path, :1141-1148) -> VDB_ERR_UNSUPPORTED. */
+int vdb_search_batch_device(const vdb_index* idx, const float* d_queries, size_t nq, size_t k,
+                            float* d_out_dist, uint64_t* d_out_label, uint32_t* d_out_stats, void* stream);
+/* Same with HOST pointers (copies in and out, synchronises; PCIe-inclusive). */
+int vdb_search_batch(const vdb_index* idx, const float* queries, size_t nq, size_t k, float* out_dist,
+                     uint64_t* out_label, uint32_t* out_stats);
+
+/* ---- BruteforceSearch<float> ------------------------------------------------------ */
+
+/* ctor BruteforceSearch(space, maxElements), bruteforce.hpp:54-65. */
+int vdb_bf_create(vdb_bruteforce** out, int metric, size_t dim, size_t capacity);
+/* loadIndex / saveIndex, bruteforce.hpp:190-231. */
+int vdb_bf_load(vdb_bruteforce** out, const char* path, int metric, size_t dim);
+int vdb_bf_save(const vdb_bruteforce* bf, const char* path);
+void vdb_bf_free(vdb_bruteforce* bf);
+/* addPoint / removePoint, bruteforce.hpp:84-138. */
+int vdb_bf_add_batch(vdb_bruteforce* bf, const float* vecs, const uint64_t* labels, size_t n);
+int vdb_bf_remove(vdb_bruteforce* bf, uint64_t label);
+size_t vdb_bf_count(const vdb_bruteforce* bf);
+/* Upload rows + labels (+ norms) to `device`. */
+int vdb_bf_to_device(vdb_bruteforce* bf, int device);
+/* SearchKNN (bruteforce.hpp:147-184) closest first over a batch: the k smallest
+ * (dist, label) pairs per query.  Device pointers as vdb_search_batch_device. */
+int vdb_bf_search_batch_device(const vdb_bruteforce* bf, const float* d_queries, size_t nq, size_t k,
+                               int precision, float* d_out_dist, uint64_t* d_out_label, void* stream);
+int vdb_bf_search_batch(const vdb_bruteforce* bf, const float* queries, size_t nq, size_t k, int precision,
+                        float* out_dist, uint64_t* out_label);
+
+/* ---- shard merge (no reference counterpart) --------------------------- */
+
+/* Merge G per-shard result lists into one: inputs [G][nq][k] (each row ascending, padded
+ * with +inf/UINT64_MAX), output [nq][k] = the k smallest (dist, label).  All DEVICE. */
+int vdb_merge_topk_device(const float* d_dist, const uint64_t* d_label, size_t n_lists, size_t nq, size_t k,
+                          float* d_out_dist, uint64_t* d_out_label, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDB_INDEX_H */

@@ -1,0 +1,269 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle*.so) and the reference fragments.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under vectordb_amd/ imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+L2, IP = 0, 1
+SEQ, TREE64 = 0, 1
+
+_libs: dict[str, C.CDLL] = {}
+
+
+def build(force: bool = False) -> None:
+    """Compile the oracle (and oracle/_ref when /root/reference is present)."""
+    need = force or not all(os.path.exists(os.path.join(HERE, f)) for f in ("liboracle.so", "liboracle_o3.so"))
+    ref_present = os.path.isdir("/root/reference/src/hnsw/hnsw_scratch")
+    need = need or (ref_present and not os.path.exists(os.path.join(HERE, "_ref", "libref_fragments.so")))
+    if need or _stale():
+        subprocess.check_call(["make", "-C", HERE, "all"], stdout=subprocess.DEVNULL)
+
+
+def _stale() -> bool:
+    try:
+        so = os.path.getmtime(os.path.join(HERE, "liboracle.so"))
+    except OSError:
+        return True
+    return any(os.path.getmtime(os.path.join(HERE, f)) > so for f in ("vdb_oracle.hpp", "oracle_capi.cpp"))
+
+
+def _sig(lib):
+    f32p, szp, u32p, u64p = (C.POINTER(C.c_float), C.POINTER(C.c_size_t), C.POINTER(C.c_uint), C.POINTER(C.c_uint64))
+    lib.orc_last_error.restype = C.c_char_p
+    lib.orc_distance.restype = C.c_float
+    lib.orc_distance.argtypes = [C.c_int, C.c_int, f32p, f32p, C.c_size_t]
+    lib.orc_visited_tags.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_ushort), C.POINTER(C.c_int)]
+    lib.orc_hnsw_create.restype = C.c_void_p
+    lib.orc_hnsw_create.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
+    lib.orc_hnsw_load.restype = C.c_void_p
+    lib.orc_hnsw_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_size_t]
+    lib.orc_hnsw_free.argtypes = [C.c_void_p]
+    lib.orc_hnsw_save.argtypes = [C.c_void_p, C.c_char_p]
+    lib.orc_hnsw_add.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_int]
+    lib.orc_hnsw_add_batch.argtypes = [C.c_void_p, f32p, szp, C.c_size_t]
+    lib.orc_hnsw_set_ef.argtypes = [C.c_void_p, C.c_size_t]
+    lib.orc_hnsw_set_mode.argtypes = [C.c_void_p, C.c_int]
+    for name in ("count", "capacity", "deleted"):
+        fn = getattr(lib, f"orc_hnsw_{name}")
+        fn.restype = C.c_size_t
+        fn.argtypes = [C.c_void_p]
+    lib.orc_hnsw_max_level.argtypes = [C.c_void_p]
+    lib.orc_hnsw_entry.restype = C.c_uint
+    lib.orc_hnsw_entry.argtypes = [C.c_void_p]
+    lib.orc_hnsw_level_of.argtypes = [C.c_void_p, C.c_uint]
+    lib.orc_hnsw_check_integrity.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.orc_hnsw_mark_delete.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    lib.orc_hnsw_links.argtypes = [C.c_void_p, C.c_uint, C.c_int, u32p, C.c_int]
+    lib.orc_hnsw_search.restype = C.c_double
+    lib.orc_hnsw_search.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, f32p, szp, u32p, u64p, u64p, u64p,
+                                    C.c_int, C.c_size_t, C.c_size_t]
+    lib.orc_bf_create.restype = C.c_void_p
+    lib.orc_bf_create.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t]
+    lib.orc_bf_load.restype = C.c_void_p
+    lib.orc_bf_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_size_t]
+    lib.orc_bf_free.argtypes = [C.c_void_p]
+    lib.orc_bf_save.argtypes = [C.c_void_p, C.c_char_p]
+    lib.orc_bf_add_batch.argtypes = [C.c_void_p, f32p, szp, C.c_size_t]
+    lib.orc_bf_remove.argtypes = [C.c_void_p, C.c_size_t]
+    lib.orc_bf_count.restype = C.c_size_t
+    lib.orc_bf_count.argtypes = [C.c_void_p]
+    lib.orc_bf_search.restype = C.c_double
+    lib.orc_bf_search.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, f32p, szp, u32p, C.c_int, C.c_size_t,
+                                  C.c_size_t]
+    return lib
+
+
+def lib(o3: bool = False) -> C.CDLL:
+    name = "liboracle_o3.so" if o3 else "liboracle.so"
+    if name not in _libs:
+        path = os.path.join(HERE, name)
+        if not os.path.exists(path):
+            build()
+        _libs[name] = _sig(C.CDLL(path))
+    return _libs[name]
+
+
+def ref_fragments():
+    """The reference's own compilable fragments (oracle/_ref), or None if never built."""
+    path = os.path.join(HERE, "_ref", "libref_fragments.so")
+    if not os.path.exists(path):
+        return None
+    if "ref" not in _libs:
+        r = C.CDLL(path)
+        f32p, szp = C.POINTER(C.c_float), C.POINTER(C.c_size_t)
+        r.ref_l2sqr.restype = C.c_float
+        r.ref_l2sqr.argtypes = [f32p, f32p, C.c_size_t]
+        r.ref_ipdist.restype = C.c_float
+        r.ref_ipdist.argtypes = [f32p, f32p, C.c_size_t]
+        r.ref_visited_tags.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_ushort), C.POINTER(C.c_int)]
+        r.ref_closer_first.argtypes = [f32p, szp, C.c_size_t, f32p, szp]
+        _libs["ref"] = r
+    return _libs["ref"]
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _sz(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_size_t))
+
+
+def distance(metric: int, mode: int, a, b) -> float:
+    a, pa = _f32(a)
+    b, pb = _f32(b)
+    return float(lib().orc_distance(metric, mode, pa, pb, a.size))
+
+
+def _err(l) -> str:
+    return l.orc_last_error().decode()
+
+
+class OracleHNSW:
+    """The restated HierarchicalNSW<float> (hnsw_core.hpp:21)."""
+
+    def __init__(self, metric: int, dim: int, capacity: int = 0, M: int = 16, ef_construction: int = 200,
+                 seed: int = 100, mode: int = SEQ, o3: bool = False, path: str | None = None):
+        self._l = lib(o3)
+        self.metric, self.dim = metric, dim
+        if path is not None:
+            self._h = self._l.orc_hnsw_load(path.encode(), metric, mode, dim)
+        else:
+            self._h = self._l.orc_hnsw_create(metric, mode, dim, capacity, M, ef_construction, seed)
+        if not self._h:
+            raise RuntimeError(_err(self._l))
+
+    @classmethod
+    def load(cls, path: str, metric: int, dim: int, mode: int = SEQ, o3: bool = False) -> "OracleHNSW":
+        return cls(metric, dim, mode=mode, o3=o3, path=path)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._l.orc_hnsw_free(self._h)
+            self._h = None
+
+    def add(self, vecs, labels=None) -> None:
+        vecs, pv = _f32(vecs)
+        n = vecs.shape[0]
+        pl = None
+        if labels is not None:
+            labels, pl = _sz(labels)
+        if self._l.orc_hnsw_add_batch(self._h, pv, pl, n) != 0:
+            raise RuntimeError(_err(self._l))
+
+    def add_one(self, vec, label: int, level: int = -1) -> None:
+        vec, pv = _f32(vec)
+        if self._l.orc_hnsw_add(self._h, pv, label, level) != 0:
+            raise RuntimeError(_err(self._l))
+
+    def save(self, path: str) -> None:
+        if self._l.orc_hnsw_save(self._h, path.encode()) != 0:
+            raise RuntimeError(_err(self._l))
+
+    def set_ef(self, ef: int) -> None:
+        self._l.orc_hnsw_set_ef(self._h, ef)
+
+    def set_mode(self, mode: int) -> None:
+        self._l.orc_hnsw_set_mode(self._h, mode)
+
+    def mark_delete(self, label: int) -> None:
+        if self._l.orc_hnsw_mark_delete(self._h, label, 0) != 0:
+            raise RuntimeError(_err(self._l))
+
+    def unmark_delete(self, label: int) -> None:
+        if self._l.orc_hnsw_mark_delete(self._h, label, 1) != 0:
+            raise RuntimeError(_err(self._l))
+
+    count = property(lambda s: s._l.orc_hnsw_count(s._h))
+    capacity = property(lambda s: s._l.orc_hnsw_capacity(s._h))
+    deleted = property(lambda s: s._l.orc_hnsw_deleted(s._h))
+    max_level = property(lambda s: s._l.orc_hnsw_max_level(s._h))
+    entry = property(lambda s: s._l.orc_hnsw_entry(s._h))
+
+    def level_of(self, i: int) -> int:
+        return self._l.orc_hnsw_level_of(self._h, i)
+
+    def links(self, i: int, level: int) -> list[int]:
+        buf = (C.c_uint * 4096)()
+        n = self._l.orc_hnsw_links(self._h, i, level, buf, 4096)
+        return list(buf[:n])
+
+    def check_integrity(self):
+        mn, mx = C.c_int(0), C.c_int(0)
+        rc = self._l.orc_hnsw_check_integrity(self._h, C.byref(mn), C.byref(mx))
+        return rc, mn.value, mx.value
+
+    def search(self, queries, k: int, n_threads: int = 1, filter_mod: int = 0, filter_keep: int = 0):
+        """-> dict(dist [nq,k] f32, label [nq,k] u64, count, ndis, nhops0, nhops_upper, seconds)"""
+        queries, pq = _f32(queries)
+        nq = queries.shape[0]
+        dist = np.empty((nq, k), np.float32)
+        label = np.empty((nq, k), np.uint64)
+        count = np.empty(nq, np.uint32)
+        ndis, nh0, nhu = (np.empty(nq, np.uint64) for _ in range(3))
+        u64p = C.POINTER(C.c_uint64)
+        secs = self._l.orc_hnsw_search(
+            self._h, pq, nq, k, dist.ctypes.data_as(C.POINTER(C.c_float)), label.ctypes.data_as(C.POINTER(C.c_size_t)),
+            count.ctypes.data_as(C.POINTER(C.c_uint)), ndis.ctypes.data_as(u64p), nh0.ctypes.data_as(u64p),
+            nhu.ctypes.data_as(u64p), n_threads, filter_mod, filter_keep)
+        if secs < 0:
+            raise RuntimeError(_err(self._l))
+        return dict(dist=dist, label=label, count=count, ndis=ndis, nhops0=nh0, nhops_upper=nhu, seconds=secs)
+
+
+class OracleBruteforce:
+    """The restated BruteforceSearch<float> (bruteforce.hpp:14)."""
+
+    def __init__(self, metric: int, dim: int, capacity: int = 0, mode: int = SEQ, o3: bool = False,
+                 path: str | None = None):
+        self._l = lib(o3)
+        self.metric, self.dim = metric, dim
+        if path is not None:
+            self._h = self._l.orc_bf_load(path.encode(), metric, mode, dim)
+        else:
+            self._h = self._l.orc_bf_create(metric, mode, dim, capacity)
+        if not self._h:
+            raise RuntimeError(_err(self._l))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._l.orc_bf_free(self._h)
+            self._h = None
+
+    def add(self, vecs, labels=None) -> None:
+        vecs, pv = _f32(vecs)
+        pl = None
+        if labels is not None:
+            labels, pl = _sz(labels)
+        if self._l.orc_bf_add_batch(self._h, pv, pl, vecs.shape[0]) != 0:
+            raise RuntimeError(_err(self._l))
+
+    def remove(self, label: int) -> None:
+        self._l.orc_bf_remove(self._h, label)
+
+    def save(self, path: str) -> None:
+        if self._l.orc_bf_save(self._h, path.encode()) != 0:
+            raise RuntimeError(_err(self._l))
+
+    count = property(lambda s: s._l.orc_bf_count(s._h))
+
+    def search(self, queries, k: int, n_threads: int = 1, filter_mod: int = 0, filter_keep: int = 0):
+        queries, pq = _f32(queries)
+        nq = queries.shape[0]
+        dist = np.empty((nq, k), np.float32)
+        label = np.empty((nq, k), np.uint64)
+        count = np.empty(nq, np.uint32)
+        secs = self._l.orc_bf_search(self._h, pq, nq, k, dist.ctypes.data_as(C.POINTER(C.c_float)),
+                                     label.ctypes.data_as(C.POINTER(C.c_size_t)),
+                                     count.ctypes.data_as(C.POINTER(C.c_uint)), n_threads, filter_mod, filter_keep)
+        return dict(dist=dist, label=label, count=count, seconds=secs)
