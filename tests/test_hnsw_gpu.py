@@ -1,0 +1,124 @@
+"""GPU parity of the traversal: device search == oracle search on the same graph, neighbour
+ids AND distances bit for bit, plus the reference's work counters (ndis / hops)."""
+import numpy as np
+import pytest
+
+from tests.helpers import assert_same_results, build_pair
+from vectordb_amd import datasets
+from vectordb_amd import index as vi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,dim,M,efc,metric", [
+    (2000, 128, 16, 100, vi.L2),
+    (1500, 16, 4, 32, vi.L2),
+    (1200, 96, 16, 100, vi.IP),
+    (800, 40, 8, 64, vi.L2),      # ragged dim: not a multiple of 16 / 32 / 64
+    (600, 200, 12, 64, vi.IP),    # 4 chunks, maxM0 = 24
+    (300, 960, 16, 64, vi.L2),    # GIST-like rows: 15 chunks
+])
+def test_search_matches_oracle(orc, n, dim, M, efc, metric):
+    x = datasets.uniform(n, dim, 1)
+    q = datasets.uniform(64, dim, 2)
+    if metric == vi.IP:
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+    h, o = build_pair(orc, x, metric, M, efc)
+    h.to_device(0)
+    for ef in (8, 16, 64, 100, 200):
+        for k in (1, 10):
+            h.setefSearch(ef)
+            o.set_ef(ef)
+            dist, label, st = h.search_batch(q, k, stats=True)
+            assert_same_results((dist, label), o.search(q, k), st)
+
+
+def test_clustered_c1_like(orc):
+    x = datasets.clustered(4000, 128, 1)
+    q = datasets.clustered(200, 128, 2)
+    h, o = build_pair(orc, x, vi.L2, 16, 200)
+    h.to_device(0)
+    h.setefSearch(64)
+    o.set_ef(64)
+    dist, label, st = h.search_batch(q, 10, stats=True)
+    assert_same_results((dist, label), o.search(q, 10), st)
+
+
+def test_labels_not_ids_and_ties(orc):
+    """Duplicate vectors force exact distance ties: eviction order (dist, id), output order
+    (dist, label) with labels running AGAINST ids."""
+    rng = np.random.default_rng(5)
+    base = rng.random((40, 24), dtype=np.float32)
+    x = np.concatenate([base] * 12, axis=0)           # every vector 12 times
+    perm = rng.permutation(x.shape[0])
+    x = x[perm]
+    labels = (10_000_000_000 - np.arange(x.shape[0])).astype(np.uint64)  # descending, > 2^32
+    q = np.concatenate([base[:20], rng.random((20, 24), dtype=np.float32)])
+    h, o = build_pair(orc, x, vi.L2, 8, 64, labels=labels)
+    h.to_device(0)
+    for ef, k in ((10, 10), (16, 5), (64, 10), (64, 30), (100, 100)):
+        h.setefSearch(ef)
+        o.set_ef(ef)
+        dist, label, st = h.search_batch(q, k, stats=True)
+        assert_same_results((dist, label), o.search(q, k), st)
+
+
+def test_small_and_empty_indexes(orc):
+    dim = 32
+    q = datasets.uniform(5, dim, 3)
+    # empty index -> every row padded (hnsw_core.hpp:1109)
+    h, o = build_pair(orc, np.zeros((0, dim), np.float32))
+    h.to_device(0)
+    dist, label, st = h.search_batch(q, 3, stats=True)
+    assert np.all(np.isinf(dist)) and np.all(label == np.uint64(2**64 - 1)) and np.all(st == 0)
+    # fewer elements than k
+    x = datasets.uniform(7, dim, 4)
+    h, o = build_pair(orc, x, M=4, efc=16)
+    h.to_device(0)
+    h.setefSearch(10)
+    o.set_ef(10)
+    dist, label, st = h.search_batch(q, 10, stats=True)
+    assert_same_results((dist, label), o.search(q, 10), st)
+    assert np.all(st[:, 3] == 7)
+
+
+def test_visited_overflow_falls_back_exactly(orc):
+    """ef large against a small hash is what the large configuration is for: ef=256 on a
+    graph of 6000 nodes visits most of it."""
+    x = datasets.uniform(6000, 16, 11)
+    q = datasets.uniform(32, 16, 12)
+    h, o = build_pair(orc, x, vi.L2, 16, 64)
+    h.to_device(0)
+    h.setefSearch(256)
+    o.set_ef(256)
+    dist, label, st = h.search_batch(q, 100, stats=True)
+    assert_same_results((dist, label), o.search(q, 100), st)
+
+
+def test_device_pointer_api_and_errors(orc):
+    import torch
+    x = datasets.uniform(1000, 64, 1)
+    q = datasets.uniform(100, 64, 2)
+    h, o = build_pair(orc, x, vi.L2, 16, 64)
+    with pytest.raises(vi.VdbError) as e:
+        h.search_batch(q, 10)                      # not uploaded yet
+    assert e.value.code == 3
+    h.to_device(0)
+    h.setefSearch(32)
+    o.set_ef(32)
+    tq = torch.from_numpy(q).cuda()
+    dist, label = h.search_batch(tq, 10)
+    torch.cuda.synchronize()
+    ref = o.search(q, 10)
+    np.testing.assert_array_equal(label.cpu().numpy().view(np.uint64), ref["label"].astype(np.uint64))
+    np.testing.assert_array_equal(dist.cpu().numpy().view(np.uint32), ref["dist"].view(np.uint32))
+    h.setefSearch(300)
+    with pytest.raises(vi.VdbError) as e:
+        h.search_batch(q, 10)
+    assert e.value.code == 4
+    h.setefSearch(32)
+    h.addPoint(x[0] + 1.0, 5000) if h.getCapacity() > 1000 else None
+    h.markDelete(3)
+    with pytest.raises(vi.VdbError):
+        h.search_batch(q, 10)                      # stale device copy / deleted elements

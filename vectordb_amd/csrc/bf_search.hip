@@ -1,0 +1,383 @@
+// bf_search.hip — gfx950 kernels for BruteforceSearch::SearchKNN and the shard merge.
+//
+// Reference path (src/hnsw/hnsw_scratch/bruteforce.hpp:147-184): linear scan, admit on
+// `dist <= lastdist`, max-heap of (dist, label) under the default pair order -> the answer is
+// the k smallest (dist, label) pairs; SearchKNNCloserFirst (hnswlib.hpp:87-99) returns them
+// ascending.  Distances: space_l2.hpp:1-14 / space_ip.hpp:3-18 in the tree64 summation order
+// (DESIGN.md "Numerics"), bit-identical to the traversal kernels and to the oracle.
+//
+// Exact scan (VDB_BF_FP32):
+//   bf_scan_exact   a block stages a tile of queries in LDS (tree64 register layout), every
+//                   16-lane group holds one base row in registers and scores it against each
+//                   staged query; pairs with dist <= tau[q] are appended to the query's
+//                   candidate buffer in HBM.
+//   bf_compact      one wave per query: bitonic-sorts the buffer in LDS, keeps the k smallest
+//                   (dist, label), publishes tau[q] = k-th distance for the next slab.
+// The base set is swept in slabs of (capacity - k) rows, so a buffer can never overflow: the
+// result is exact for any data order, duplicates included.
+//
+//   merge_topk      shard merge: G ascending lists per query -> the k smallest
+//                   (dist, label); one wave per query, rank by counting.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "device_index.hpp"
+#include "launch.hpp"
+
+namespace vdb {
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t u) {
+    return __builtin_bit_cast(float, (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ------------------------------------------------------------------ exact scan
+
+struct ScanArgs {
+    const float* base;     // [n][vstride], rows zero-padded
+    const float* queries;  // [nq][dim]
+    uint32_t dim, vstride, nq, qt;  // qt = queries per block
+    uint32_t row_lo, row_hi;        // slab
+    int32_t metric;
+    uint32_t cap;                   // entries per query buffer
+    uint32_t* count;                // [nq]
+    const uint32_t* tau;            // [nq] ordered-u32 threshold
+    uint64_t* entries;              // [nq][cap]  ord(dist) << 32 | row
+};
+
+constexpr int kScanRowsPerBlock = 256;  // 4 waves x 16 steps x 4 rows
+
+template <int NCH>
+__global__ __launch_bounds__(256) void bf_scan_exact(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_q[];  // [qt][vstride] then tau[qt]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = lane >> 4, t = lane & 15;
+    const uint32_t q0 = blockIdx.y * a.qt;
+    const uint32_t nqt = a.nq - q0 < a.qt ? a.nq - q0 : a.qt;
+    uint32_t* s_tau = reinterpret_cast<uint32_t*>(s_q + (size_t)a.qt * a.vstride);
+
+    for (uint32_t i = tid; i < nqt * a.vstride; i += 256) {
+        const uint32_t qi = i / a.vstride, e = i - qi * a.vstride;
+        s_q[i] = e < a.dim ? a.queries[(size_t)(q0 + qi) * a.dim + e] : 0.f;
+    }
+    for (uint32_t i = tid; i < nqt; i += 256) s_tau[i] = a.tau[q0 + i];
+    __syncthreads();
+
+    const bool is_l2 = a.metric == 0;
+    const uint32_t block_row = a.row_lo + blockIdx.x * kScanRowsPerBlock;
+#pragma unroll 1
+    for (int step = 0; step < 16; ++step) {
+        const uint32_t row = block_row + (uint32_t)((wave * 16 + step) * 4 + grp);
+        if (block_row + (uint32_t)((wave * 16 + step) * 4) >= a.row_hi) break;  // wave-uniform
+        const bool live = row < a.row_hi;
+        f32x4 x[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            x[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (live && (uint32_t)(64 * j + 4 * t) < a.vstride)
+                x[j] = *reinterpret_cast<const f32x4*>(a.base + (size_t)row * a.vstride + 64 * j + 4 * t);
+        }
+#pragma unroll 1
+        for (uint32_t qi = 0; qi < nqt; ++qi) {
+            const float* qrow = s_q + (size_t)qi * a.vstride + 4 * t;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
+                if ((uint32_t)(64 * j + 4 * t) < a.vstride) q = *reinterpret_cast<const f32x4*>(qrow + 64 * j);
+                if (is_l2) {
+                    const float d0 = q.x - x[j].x, d1 = q.y - x[j].y, d2 = q.z - x[j].z, d3 = q.w - x[j].w;
+                    a0 = __builtin_fmaf(d0, d0, a0);
+                    a1 = __builtin_fmaf(d1, d1, a1);
+                    a2 = __builtin_fmaf(d2, d2, a2);
+                    a3 = __builtin_fmaf(d3, d3, a3);
+                } else {
+                    a0 = __builtin_fmaf(q.x, x[j].x, a0);
+                    a1 = __builtin_fmaf(q.y, x[j].y, a1);
+                    a2 = __builtin_fmaf(q.z, x[j].z, a2);
+                    a3 = __builtin_fmaf(q.w, x[j].w, a3);
+                }
+            }
+            float s = (a0 + a1) + (a2 + a3);
+            s = s + dpp_f32<kDppXor1>(s);
+            s = s + dpp_f32<kDppXor2>(s);
+            s = s + dpp_f32<kDppHalfMirror>(s);
+            s = s + dpp_f32<kDppMirror>(s);
+            if (!is_l2) s = 1.0f - s;
+            const uint32_t od = f2ord(s);
+            if (t == 0 && live && od <= s_tau[qi]) {  // bruteforce.hpp:167 `dist <= lastdist`
+                const uint32_t pos = atomicAdd(&a.count[q0 + qi], 1u);
+                if (pos < a.cap) a.entries[(size_t)(q0 + qi) * a.cap + pos] = ((uint64_t)od << 32) | row;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ compaction / output
+
+struct CompactArgs {
+    uint32_t nq, k, cap;
+    uint32_t* count;
+    uint32_t* tau;
+    uint64_t* entries;
+    const uint64_t* labels;  // [n] label of a row
+    int32_t final_pass;
+    float* out_dist;         // [nq][k]   (final pass)
+    uint64_t* out_label;     // [nq][k]
+};
+
+// ascending bitonic sort of p (power of two, >= 64) keys in LDS by one wave
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t* s, uint32_t p, int lane) {
+    for (uint32_t size = 2; size <= p; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t i = lane; i < (p >> 1); i += 64) {
+                const uint32_t lo = ((i & ~(stride - 1)) << 1) | (i & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t x = s[lo], y = s[hi];
+                if ((x > y) == up) {
+                    s[lo] = y;
+                    s[hi] = x;
+                }
+            }
+            wave_sync();
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void bf_compact(CompactArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_key[];  // [cap]
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    const uint32_t k = a.k;
+    uint32_t cnt = a.count[q];
+    if (cnt > a.cap) cnt = a.cap;  // cannot happen: slabs are sized so that buffers never overflow
+    uint64_t* ent = a.entries + (size_t)q * a.cap;
+
+    uint32_t p = 64;
+    while (p < cnt) p <<= 1;
+    for (uint32_t i = lane; i < p; i += 64) s_key[i] = i < cnt ? ent[i] : ~0ull;
+    wave_sync();
+    bitonic_sort_lds(s_key, p, lane);
+
+    // the k smallest by (dist, row) are s_key[0..k); the reference orders ties by label
+    uint32_t keep = cnt < k ? cnt : k;
+    if (cnt > k) {
+        const uint32_t dk = (uint32_t)(s_key[k - 1] >> 32);
+        if ((uint32_t)(s_key[k] >> 32) == dk) {
+            // a group of equal distances straddles the cut: keep its smallest labels
+            uint32_t ga = k - 1, gb = k;
+            while (ga > 0 && (uint32_t)(s_key[ga - 1] >> 32) == dk) --ga;
+            while (gb < cnt && (uint32_t)(s_key[gb] >> 32) == dk) ++gb;
+            const uint32_t want = k - ga;
+            // rank by label inside the group; winners are rewritten in place behind ga
+            // (two phases so that no lane overwrites a key another lane still reads)
+            uint64_t* scratch = ent;  // the HBM buffer is free to use: its content now lives in LDS
+            for (uint32_t i = ga + lane; i < gb; i += 64) {
+                const uint64_t li = a.labels[(uint32_t)s_key[i]];
+                uint32_t rank = 0;
+                for (uint32_t j = ga; j < gb; ++j) rank += a.labels[(uint32_t)s_key[j]] < li ? 1u : 0u;
+                if (rank < want) scratch[ga + rank] = s_key[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            wave_sync();
+            for (uint32_t i = ga + lane; i < k; i += 64) s_key[i] = scratch[i];
+            wave_sync();
+        }
+    }
+
+    if (!a.final_pass) {
+        for (uint32_t i = lane; i < keep; i += 64) ent[i] = s_key[i];
+        if (lane == 0) {
+            a.count[q] = keep;
+            a.tau[q] = keep == k ? (uint32_t)(s_key[k - 1] >> 32) : 0xFFFFFFFFu;
+        }
+        return;
+    }
+    // final: ascending (dist, label)
+    float* od = a.out_dist + (size_t)q * k;
+    uint64_t* ol = a.out_label + (size_t)q * k;
+    for (uint32_t i = lane; i < keep; i += 64) {
+        const uint32_t di = (uint32_t)(s_key[i] >> 32);
+        const uint64_t li = a.labels[(uint32_t)s_key[i]];
+        uint32_t pos = i;
+        const bool tie = (i > 0 && (uint32_t)(s_key[i - 1] >> 32) == di) || (i + 1 < keep && (uint32_t)(s_key[i + 1] >> 32) == di);
+        if (tie) {
+            uint32_t lo = i;
+            while (lo > 0 && (uint32_t)(s_key[lo - 1] >> 32) == di) --lo;
+            pos = lo;
+            for (uint32_t j = lo; j < keep && (uint32_t)(s_key[j] >> 32) == di; ++j)
+                pos += a.labels[(uint32_t)s_key[j]] < li ? 1u : 0u;
+        }
+        od[pos] = ord2f(di);
+        ol[pos] = li;
+    }
+    for (uint32_t i = keep + lane; i < k; i += 64) {
+        od[i] = __builtin_inff();
+        ol[i] = ~0ull;
+    }
+}
+
+// ------------------------------------------------------------------ shard merge
+
+struct MergeArgs {
+    const float* dist;      // [G][nq][k]
+    const uint64_t* label;  // [G][nq][k]
+    uint32_t G, nq, k;
+    float* out_dist;        // [nq][k]
+    uint64_t* out_label;
+};
+
+__global__ __launch_bounds__(64) void merge_topk_kernel(MergeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_m[];  // [G k] labels, then [G k] u32 ord dist
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x, total = a.G * a.k;
+    uint64_t* s_lab = s_m;
+    uint32_t* s_d = reinterpret_cast<uint32_t*>(s_m + total);
+    for (uint32_t i = lane; i < total; i += 64) {
+        const uint32_t gi = i / a.k, j = i - gi * a.k;
+        const size_t src = ((size_t)gi * a.nq + q) * a.k + j;
+        s_d[i] = f2ord(a.dist[src]);
+        s_lab[i] = a.label[src];
+    }
+    wave_sync();
+    for (uint32_t i = lane; i < total; i += 64) {
+        const uint32_t di = s_d[i];
+        const uint64_t li = s_lab[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < total; ++j) {
+            const uint32_t dj = s_d[j];
+            const uint64_t lj = s_lab[j];
+            const bool less = dj < di || (dj == di && (lj < li || (lj == li && j < i)));
+            rank += less ? 1u : 0u;
+        }
+        if (rank < a.k) {
+            a.out_dist[(size_t)q * a.k + rank] = ord2f(di);
+            a.out_label[(size_t)q * a.k + rank] = li;
+        }
+    }
+}
+
+template <int NCH>
+void launch_scan(const ScanArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
+    hipLaunchKernelGGL((bf_scan_exact<NCH>), grid, dim3(256), lds, stream, a);
+}
+
+}  // namespace
+
+size_t bf_exact_workspace_bytes(uint32_t nq) { return (size_t)nq * (8 + (size_t)kBfCap * 8); }
+
+int launch_bf_exact(const float* d_base, const uint64_t* d_labels, uint32_t n, uint32_t dim, uint32_t vstride,
+                    int metric, const float* d_queries, uint32_t nq, uint32_t k, float* d_out_dist,
+                    uint64_t* d_out_label, void* workspace, hipStream_t stream, std::string* err) {
+    if (nq == 0) return 0;
+    if (k == 0 || k > kBfMaxK) {
+        if (err) *err = "brute force: k must be in 1..1024";
+        return 4;
+    }
+    if (vstride > kMaxVecStride) {
+        if (err) *err = "dim above 1024 is not supported by the device path";
+        return 4;
+    }
+    uint32_t* count = static_cast<uint32_t*>(workspace);
+    uint32_t* tau = count + nq;
+    uint64_t* entries = reinterpret_cast<uint64_t*>(tau + nq);  // nq*8 bytes in: 8-byte aligned
+    hipError_t e = hipMemsetAsync(count, 0, (size_t)nq * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(tau, 0xFF, (size_t)nq * 4, stream);
+
+    ScanArgs s{};
+    s.base = d_base;
+    s.queries = d_queries;
+    s.dim = dim;
+    s.vstride = vstride;
+    s.nq = nq;
+    uint32_t qt = (uint32_t)((48u * 1024u) / ((size_t)vstride * 4));
+    if (qt > 64) qt = 64;
+    if (qt < 1) qt = 1;
+    s.qt = qt;
+    s.metric = metric;
+    s.cap = kBfCap;
+    s.count = count;
+    s.tau = tau;
+    s.entries = entries;
+    const size_t scan_lds = (size_t)qt * vstride * 4 + (size_t)qt * 4;
+
+    CompactArgs c{};
+    c.nq = nq;
+    c.k = k;
+    c.cap = kBfCap;
+    c.count = count;
+    c.tau = tau;
+    c.entries = entries;
+    c.labels = d_labels;
+    c.out_dist = d_out_dist;
+    c.out_label = d_out_label;
+
+    const uint32_t slab = kBfCap - k;
+    const uint32_t nch = (vstride + 63u) / 64u;
+    uint32_t lo = 0;
+    do {
+        const uint32_t hi = n - lo > slab ? lo + slab : n;
+        if (hi > lo && e == hipSuccess) {
+            s.row_lo = lo;
+            s.row_hi = hi;
+            const dim3 grid((hi - lo + kScanRowsPerBlock - 1) / kScanRowsPerBlock, (nq + qt - 1) / qt);
+            if (nch <= 1) launch_scan<1>(s, grid, scan_lds, stream);
+            else if (nch <= 2) launch_scan<2>(s, grid, scan_lds, stream);
+            else if (nch <= 4) launch_scan<4>(s, grid, scan_lds, stream);
+            else if (nch <= 8) launch_scan<8>(s, grid, scan_lds, stream);
+            else launch_scan<16>(s, grid, scan_lds, stream);
+            e = hipGetLastError();
+        }
+        lo = hi;
+        c.final_pass = lo >= n ? 1 : 0;
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(bf_compact, dim3(nq), dim3(64), (size_t)kBfCap * 8, stream, c);
+            e = hipGetLastError();
+        }
+    } while (lo < n && e == hipSuccess);
+    if (e != hipSuccess) {
+        if (err) *err = std::string("brute-force launch failed: ") + hipGetErrorString(e);
+        return 3;
+    }
+    return 0;
+}
+
+int launch_merge_topk(const float* d_dist, const uint64_t* d_label, uint32_t n_lists, uint32_t nq, uint32_t k,
+                      float* d_out_dist, uint64_t* d_out_label, hipStream_t stream, std::string* err) {
+    if (nq == 0 || k == 0) return 0;
+    const size_t lds = (size_t)n_lists * k * 12;
+    if (n_lists == 0 || lds > 64 * 1024) {
+        if (err) *err = "merge: n_lists * k must be in 1..5461";
+        return 1;
+    }
+    MergeArgs a{d_dist, d_label, n_lists, nq, k, d_out_dist, d_out_label};
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(64), lds, stream, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (err) *err = std::string("merge launch failed: ") + hipGetErrorString(e);
+        return 3;
+    }
+    return 0;
+}
+
+}  // namespace vdb

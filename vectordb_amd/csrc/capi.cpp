@@ -1,0 +1,678 @@
+// capi.cpp — the C-ABI of include/vdb_index.h: host index objects, the HBM copy of an
+// index, and the enqueueing of the gfx950 kernels.  No CPU search lives here: every search
+// entry point runs the kernels or fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/vdb_index.h"
+#include "device_index.hpp"
+#include "host_index.hpp"
+#include "launch.hpp"
+
+using namespace vdb;
+
+namespace {
+
+thread_local std::string g_error;
+
+int set_error(int code, const std::string& msg) {
+    g_error = msg;
+    return code;
+}
+
+#define VDB_HIP(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) throw DeviceError(std::string(#call) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+struct DeviceError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+struct Unsupported : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+template <typename F>
+int guarded(F&& f) {
+    try {
+        return f();
+    } catch (const std::invalid_argument& e) {
+        return set_error(VDB_ERR_INVALID, e.what());
+    } catch (const DeviceError& e) {
+        return set_error(VDB_ERR_NO_DEVICE, e.what());
+    } catch (const Unsupported& e) {
+        return set_error(VDB_ERR_UNSUPPORTED, e.what());
+    } catch (const std::bad_alloc&) {
+        return set_error(VDB_ERR_RUNTIME, "Not enough memory");
+    } catch (const std::exception& e) {
+        return set_error(VDB_ERR_RUNTIME, e.what());
+    }
+}
+
+struct DeviceGuard {  // makes `dev` current for the scope, then restores the caller's device
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        VDB_HIP(hipGetDevice(&prev));
+        if (prev != dev) VDB_HIP(hipSetDevice(dev));
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    void alloc(size_t n) {
+        release();
+        if (n == 0) n = 256;
+        VDB_HIP(hipMalloc(&p, n));
+        bytes = n;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+// Per-stream scratch of the traversal (work list of re-run queries + visited bitmaps).
+struct SearchScratch {
+    DevBuf redo, bitmaps;
+    size_t redo_cap = 0;
+    uint32_t bitmap_words = 0;
+};
+
+}  // namespace
+
+struct vdb_index {
+    std::unique_ptr<HostIndex> host;
+    // device copy
+    int device = -1;
+    uint64_t device_version = ~0ull;
+    DevGraph graph{};
+    DevBuf vecs, links0, upper_row, upper_links, labels;
+    std::mutex scratch_lock;
+    std::map<hipStream_t, std::unique_ptr<SearchScratch>> scratch;
+
+    size_t device_bytes() const {
+        return device < 0 ? 0 : vecs.bytes + links0.bytes + upper_row.bytes + upper_links.bytes + labels.bytes;
+    }
+    void drop_device() {
+        if (device < 0) return;
+        try {
+            DeviceGuard g(device);
+            (void)hipDeviceSynchronize();
+            scratch.clear();
+            vecs.release();
+            links0.release();
+            upper_row.release();
+            upper_links.release();
+            labels.release();
+        } catch (...) {
+        }
+        device = -1;
+    }
+    ~vdb_index() { drop_device(); }
+};
+
+struct vdb_bruteforce {
+    std::unique_ptr<HostBruteforce> host;
+    int device = -1;
+    uint64_t device_version = ~0ull;
+    DevBuf vecs, labels;
+    uint32_t n = 0, vstride = 0;
+    std::mutex scratch_lock;
+    std::map<hipStream_t, std::unique_ptr<DevBuf>> scratch;
+
+    void drop_device() {
+        if (device < 0) return;
+        try {
+            DeviceGuard g(device);
+            (void)hipDeviceSynchronize();
+            scratch.clear();
+            vecs.release();
+            labels.release();
+        } catch (...) {
+        }
+        device = -1;
+    }
+    ~vdb_bruteforce() { drop_device(); }
+};
+
+namespace {
+
+void upload_bf(vdb_bruteforce* bf, int device) {
+    HostBruteforce& h = *bf->host;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw DeviceError("no HIP device visible");
+    if (device < 0 || device >= ndev) throw std::invalid_argument("device ordinal out of range");
+    bf->drop_device();
+    DeviceGuard guard(device);
+    std::unique_lock<std::mutex> g(h.lock);
+    const size_t n = h.count;
+    if (n >= 0xFFFFFFFFull) throw Unsupported("more than 2^32-1 rows per brute-force index (shard it)");
+    const uint32_t vstride = (uint32_t)round_up(h.dim, 32);
+    if (vstride > kMaxVecStride) throw Unsupported("dim above 1024 is not supported by the device path");
+    bf->vecs.alloc(n * (size_t)vstride * 4);
+    bf->labels.alloc(n * 8);
+    const size_t chunk = 1 << 16;
+    std::vector<float> sv(chunk * vstride, 0.f);
+    std::vector<uint64_t> sl(chunk);
+    for (size_t lo = 0; lo < n; lo += chunk) {
+        const size_t m = std::min(chunk, n - lo);
+        for (size_t i = 0; i < m; ++i) {
+            const char* r = h.data + (lo + i) * h.stride;
+            std::memcpy(sv.data() + i * vstride, r, h.data_size);
+            std::memcpy(&sl[i], r + h.data_size, 8);
+        }
+        VDB_HIP(hipMemcpy((char*)bf->vecs.p + lo * vstride * 4, sv.data(), m * vstride * 4, hipMemcpyHostToDevice));
+        VDB_HIP(hipMemcpy((char*)bf->labels.p + lo * 8, sl.data(), m * 8, hipMemcpyHostToDevice));
+    }
+    bf->n = (uint32_t)n;
+    bf->vstride = vstride;
+    bf->device = device;
+    bf->device_version = h.version;
+}
+
+// Host layout (reference byte layout) -> HBM layout of device_index.hpp, streamed in
+// chunks so that a 100 M-row index never needs a second full host copy.
+void upload(vdb_index* idx, int device) {
+    HostIndex& h = *idx->host;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw DeviceError("no HIP device visible");
+    if (device < 0 || device >= ndev) throw std::invalid_argument("device ordinal out of range");
+    idx->drop_device();
+    DeviceGuard guard(device);
+
+    const size_t n = h.count;
+    if (n >= 0x7FFFFFFFull) throw Unsupported("more than 2^31-1 elements per index (shard it)");
+    const uint32_t vstride = (uint32_t)round_up(h.dim, 32);
+    const uint32_t l0stride = (uint32_t)round_up(h.maxM0, 32);
+    const uint32_t ustride = (uint32_t)round_up(h.maxM, 16);
+    if (vstride > kMaxVecStride) throw Unsupported("dim above 1024 is not supported by the device path");
+    if (l0stride > kMaxL0Stride) throw Unsupported("M above 32 is not supported by the device path");
+
+    // upper rows: one per (node, level >= 1)
+    std::vector<uint32_t> up_row(std::max<size_t>(n, 1), kNoId);
+    size_t rows = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (h.levels[i] > 0) {
+            up_row[i] = (uint32_t)rows;
+            rows += (size_t)h.levels[i];
+        }
+    }
+    if (rows >= 0xFFFFFFFFull) throw Unsupported("too many upper-layer lists");
+
+    idx->vecs.alloc(n * (size_t)vstride * 4);
+    idx->links0.alloc(n * (size_t)l0stride * 4);
+    idx->upper_row.alloc(n * 4);
+    idx->upper_links.alloc(rows * (size_t)ustride * 4);
+    idx->labels.alloc(n * 8);
+
+    auto check_list = [&](const uint32_t* ids, unsigned cnt, size_t cap, size_t self) {
+        if (cnt > cap) throw std::runtime_error("Index seems to be corrupted: list count above its capacity");
+        for (unsigned a = 0; a < cnt; ++a) {
+            if (ids[a] >= n) throw std::runtime_error("Index seems to be corrupted: link to a non-existent element");
+            for (unsigned b = 0; b < a; ++b)
+                if (ids[a] == ids[b]) throw std::runtime_error("Index seems to be corrupted: duplicate link in a list");
+        }
+        (void)self;
+    };
+
+    const size_t chunk = 1 << 16;
+    std::vector<float> sv(chunk * vstride);
+    std::vector<uint32_t> sl(chunk * l0stride);
+    std::vector<uint64_t> slab(chunk);
+    std::vector<uint32_t> su;
+    const int n_threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    for (size_t lo = 0; lo < n; lo += chunk) {
+        const size_t m = std::min(chunk, n - lo);
+        const size_t urow_lo = [&] {
+            for (size_t i = lo; i < lo + m; ++i)
+                if (up_row[i] != kNoId) return (size_t)up_row[i];
+            return rows;
+        }();
+        size_t urow_hi = urow_lo;
+        for (size_t i = lo; i < lo + m; ++i) urow_hi += (size_t)std::max(h.levels[i], 0);
+        su.assign((urow_hi - urow_lo) * ustride, kNoId);
+
+        std::atomic<bool> bad{false};
+        std::string bad_msg;
+        std::mutex bad_lock;
+        auto work = [&](size_t a, size_t b) {
+            try {
+                for (size_t i = a; i < b; ++i) {
+                    const uint32_t id = (uint32_t)(lo + i);
+                    float* dv = sv.data() + i * vstride;
+                    std::memcpy(dv, h.vec(id), h.dim * 4);
+                    std::fill(dv + h.dim, dv + vstride, 0.f);
+                    const uint32_t* l0 = h.list0(id);
+                    const unsigned c0 = HostIndex::list_count(l0);
+                    check_list(l0 + 1, c0, h.maxM0, id);
+                    uint32_t* dl = sl.data() + i * l0stride;
+                    std::copy(l0 + 1, l0 + 1 + c0, dl);
+                    std::fill(dl + c0, dl + l0stride, kNoId);
+                    slab[i] = h.label_of(id);
+                    for (int lv = 1; lv <= h.levels[id]; ++lv) {
+                        const uint32_t* ul = h.list_at(id, lv);
+                        const unsigned cu = HostIndex::list_count(ul);
+                        check_list(ul + 1, cu, h.maxM, id);
+                        uint32_t* du = su.data() + ((size_t)up_row[id] + (size_t)(lv - 1) - urow_lo) * ustride;
+                        std::copy(ul + 1, ul + 1 + cu, du);
+                    }
+                }
+            } catch (const std::exception& e) {
+                std::unique_lock<std::mutex> g(bad_lock);
+                bad_msg = e.what();
+                bad = true;
+            }
+        };
+        std::vector<std::thread> pool;
+        const size_t per = (m + n_threads - 1) / n_threads;
+        for (int t = 0; t < n_threads; ++t) {
+            const size_t a = std::min(m, t * per), b = std::min(m, a + per);
+            if (a < b) pool.emplace_back(work, a, b);
+        }
+        for (auto& th : pool) th.join();
+        if (bad) throw std::runtime_error(bad_msg);
+
+        VDB_HIP(hipMemcpy((char*)idx->vecs.p + lo * vstride * 4, sv.data(), m * vstride * 4, hipMemcpyHostToDevice));
+        VDB_HIP(hipMemcpy((char*)idx->links0.p + lo * l0stride * 4, sl.data(), m * l0stride * 4, hipMemcpyHostToDevice));
+        VDB_HIP(hipMemcpy((char*)idx->labels.p + lo * 8, slab.data(), m * 8, hipMemcpyHostToDevice));
+        if (!su.empty())
+            VDB_HIP(hipMemcpy((char*)idx->upper_links.p + urow_lo * ustride * 4, su.data(), su.size() * 4,
+                              hipMemcpyHostToDevice));
+    }
+    if (n) VDB_HIP(hipMemcpy(idx->upper_row.p, up_row.data(), n * 4, hipMemcpyHostToDevice));
+
+    DevGraph& g = idx->graph;
+    g.vecs = (const float*)idx->vecs.p;
+    g.links0 = (const uint32_t*)idx->links0.p;
+    g.upper_row = (const uint32_t*)idx->upper_row.p;
+    g.upper_links = (const uint32_t*)idx->upper_links.p;
+    g.labels = (const uint64_t*)idx->labels.p;
+    g.n = (uint32_t)n;
+    g.dim = (uint32_t)h.dim;
+    g.vstride = vstride;
+    g.l0stride = l0stride;
+    g.ustride = ustride;
+    g.entry = h.entry;
+    g.max_level = h.max_level;
+    g.metric = h.metric;
+    idx->device = device;
+    idx->device_version = h.version;
+}
+
+SearchScratch& scratch_for(vdb_index* idx, hipStream_t stream, size_t nq) {
+    auto& slot = idx->scratch[stream];
+    if (!slot) slot.reset(new SearchScratch);
+    SearchScratch& s = *slot;
+    if (s.redo_cap < nq + 1) {
+        // a previous call on this stream may still be using the old buffer
+        if (s.redo.p) VDB_HIP(hipStreamSynchronize(stream));
+        s.redo.alloc((nq + 1) * 4 * 2);
+        s.redo_cap = (nq + 1) * 2;
+    }
+    const uint32_t words = (idx->graph.n + 31u) / 32u;
+    if (!s.bitmaps.p || s.bitmap_words < words) {
+        if (s.bitmaps.p) VDB_HIP(hipStreamSynchronize(stream));
+        s.bitmaps.alloc((size_t)kLargeBlocks * std::max(words, 1u) * 4);
+        s.bitmap_words = std::max(words, 1u);
+    }
+    return s;
+}
+
+void require_search_ready(const vdb_index* idx) {
+    if (!idx) throw std::invalid_argument("null index");
+    if (idx->device < 0) throw DeviceError("index is not on a device: call vdb_index_to_device first");
+    if (idx->device_version != idx->host->version)
+        throw DeviceError("index changed since vdb_index_to_device: upload it again");
+    if (idx->host->deleted != 0)
+        throw Unsupported("search with deleted elements (non-bare path, hnsw_core.hpp:1141-1148) is not on the device path yet");
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vdb_last_error(void) { return g_error.c_str(); }
+
+int vdb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int vdb_index_create(vdb_index** out, int metric, size_t dim, size_t capacity, size_t M, size_t efc, size_t seed) {
+    return guarded([&] {
+        if (!out) throw std::invalid_argument("null output pointer");
+        if (metric != VDB_L2 && metric != VDB_IP) throw std::invalid_argument("unknown metric");
+        std::unique_ptr<vdb_index> idx(new vdb_index);
+        idx->host.reset(new HostIndex(metric, dim, capacity, M, efc, seed));
+        *out = idx.release();
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_index_load(vdb_index** out, const char* path, int metric, size_t dim, size_t capacity) {
+    return guarded([&] {
+        if (!out || !path) throw std::invalid_argument("null argument");
+        if (metric != VDB_L2 && metric != VDB_IP) throw std::invalid_argument("unknown metric");
+        std::unique_ptr<vdb_index> idx(new vdb_index);
+        idx->host.reset(new HostIndex(std::string(path), metric, dim, capacity));
+        *out = idx.release();
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_index_save(const vdb_index* idx, const char* path) {
+    return guarded([&] {
+        if (!idx || !path) throw std::invalid_argument("null argument");
+        idx->host->save(path);
+        return (int)VDB_OK;
+    });
+}
+
+void vdb_index_free(vdb_index* idx) { delete idx; }
+
+int vdb_index_add(vdb_index* idx, const float* vec, uint64_t label, int level) {
+    return guarded([&] {
+        if (!idx || !vec) throw std::invalid_argument("null argument");
+        idx->host->add(vec, label, level);
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_index_add_batch(vdb_index* idx, const float* vecs, const uint64_t* labels, size_t n, int n_threads) {
+    return guarded([&] {
+        if (!idx || (!vecs && n)) throw std::invalid_argument("null argument");
+        idx->host->add_batch(vecs, labels, n, n_threads);
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_index_set_build_sum_order(vdb_index* idx, int order) {
+    return guarded([&] {
+        if (!idx) throw std::invalid_argument("null index");
+        if (order != VDB_SUM_SEQ && order != VDB_SUM_TREE64) throw std::invalid_argument("unknown summation order");
+        idx->host->set_sum_order(order);
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_index_set_ef(vdb_index* idx, size_t ef) {
+    return guarded([&] {
+        if (!idx) throw std::invalid_argument("null index");
+        idx->host->ef_search = ef;
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_index_mark_delete(vdb_index* idx, uint64_t label) {
+    return guarded([&] {
+        if (!idx) throw std::invalid_argument("null index");
+        idx->host->mark_delete(label, false);
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_index_unmark_delete(vdb_index* idx, uint64_t label) {
+    return guarded([&] {
+        if (!idx) throw std::invalid_argument("null index");
+        idx->host->mark_delete(label, true);
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_index_resize(vdb_index* idx, size_t new_capacity) {
+    return guarded([&] {
+        if (!idx) throw std::invalid_argument("null index");
+        idx->host->resize(new_capacity);
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_index_check_integrity(const vdb_index* idx, int* min_inbound, int* max_inbound) {
+    if (!idx) return -1;
+    return idx->host->check_integrity(min_inbound, max_inbound);
+}
+
+size_t vdb_index_capacity(const vdb_index* idx) { return idx ? idx->host->capacity : 0; }
+size_t vdb_index_count(const vdb_index* idx) { return idx ? (size_t)idx->host->count : 0; }
+size_t vdb_index_deleted_count(const vdb_index* idx) { return idx ? (size_t)idx->host->deleted : 0; }
+size_t vdb_index_dim(const vdb_index* idx) { return idx ? idx->host->dim : 0; }
+size_t vdb_index_M(const vdb_index* idx) { return idx ? idx->host->M : 0; }
+size_t vdb_index_ef(const vdb_index* idx) { return idx ? idx->host->ef_search : 0; }
+int vdb_index_max_level(const vdb_index* idx) { return idx ? idx->host->max_level : -1; }
+uint32_t vdb_index_entry(const vdb_index* idx) { return idx ? idx->host->entry : 0xFFFFFFFFu; }
+int vdb_index_level_of(const vdb_index* idx, uint32_t id) {
+    if (!idx || id >= idx->host->count) return -1;
+    return idx->host->levels[id];
+}
+int vdb_index_links(const vdb_index* idx, uint32_t id, int level, uint32_t* out, int cap) {
+    if (!idx || id >= idx->host->count || level < 0 || level > idx->host->levels[id]) return -1;
+    const uint32_t* list = idx->host->list_at(id, level);
+    const int n = (int)HostIndex::list_count(list);
+    for (int i = 0; i < n && i < cap; ++i) out[i] = list[1 + i];
+    return n;
+}
+
+int vdb_index_to_device(vdb_index* idx, int device) {
+    return guarded([&] {
+        if (!idx) throw std::invalid_argument("null index");
+        upload(idx, device);
+        return (int)VDB_OK;
+    });
+}
+
+size_t vdb_index_device_bytes(const vdb_index* idx) { return idx ? idx->device_bytes() : 0; }
+
+int vdb_search_batch_device(const vdb_index* cidx, const float* d_queries, size_t nq, size_t k, float* d_out_dist,
+                            uint64_t* d_out_label, uint32_t* d_out_stats, void* stream_) {
+    return guarded([&] {
+        vdb_index* idx = const_cast<vdb_index*>(cidx);
+        require_search_ready(idx);
+        if (nq == 0) return (int)VDB_OK;
+        if (!d_queries || !d_out_dist || !d_out_label) throw std::invalid_argument("null buffer");
+        if (k == 0) throw std::invalid_argument("k must be > 0");
+        if (nq > 0x7FFFFFFFull || k > 0x7FFFFFFFull) throw std::invalid_argument("batch too large");
+        hipStream_t stream = (hipStream_t)stream_;
+        DeviceGuard guard(idx->device);
+        const size_t ef = std::max(idx->host->ef_search, k);  // hnsw_core.hpp:1144
+        if (ef > kMaxEf) throw Unsupported("max(efSearch, k) above 256 is not supported by the device path");
+        std::unique_lock<std::mutex> lock(idx->scratch_lock);
+        SearchScratch& s = scratch_for(idx, stream, nq);
+        HnswSearchWork work;
+        work.redo = (uint32_t*)s.redo.p;
+        work.bitmaps = (uint32_t*)s.bitmaps.p;
+        work.bitmap_words = s.bitmap_words;
+        std::string err;
+        const int rc = launch_hnsw_search(idx->graph, d_queries, (uint32_t)nq, (uint32_t)k, (uint32_t)ef, d_out_dist,
+                                          d_out_label, d_out_stats, work, stream, &err);
+        if (rc != 0) return set_error(rc, err);
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_search_batch(const vdb_index* idx, const float* queries, size_t nq, size_t k, float* out_dist,
+                     uint64_t* out_label, uint32_t* out_stats) {
+    return guarded([&] {
+        require_search_ready(idx);
+        if (nq == 0) return (int)VDB_OK;
+        if (!queries || !out_dist || !out_label) throw std::invalid_argument("null buffer");
+        if (k == 0) throw std::invalid_argument("k must be > 0");
+        DeviceGuard guard(idx->device);
+        const size_t dim = idx->host->dim;
+        DevBuf dq, dd, dl, ds;
+        dq.alloc(nq * dim * 4);
+        dd.alloc(nq * k * 4);
+        dl.alloc(nq * k * 8);
+        if (out_stats) ds.alloc(nq * 16);
+        VDB_HIP(hipMemcpy(dq.p, queries, nq * dim * 4, hipMemcpyHostToDevice));
+        const int rc = vdb_search_batch_device(idx, (const float*)dq.p, nq, k, (float*)dd.p, (uint64_t*)dl.p,
+                                               out_stats ? (uint32_t*)ds.p : nullptr, nullptr);
+        if (rc != VDB_OK) return rc;
+        VDB_HIP(hipStreamSynchronize(nullptr));
+        VDB_HIP(hipMemcpy(out_dist, dd.p, nq * k * 4, hipMemcpyDeviceToHost));
+        VDB_HIP(hipMemcpy(out_label, dl.p, nq * k * 8, hipMemcpyDeviceToHost));
+        if (out_stats) VDB_HIP(hipMemcpy(out_stats, ds.p, nq * 16, hipMemcpyDeviceToHost));
+        return (int)VDB_OK;
+    });
+}
+
+// ---- BruteforceSearch<float> ----------------------------------------------------------
+
+int vdb_bf_create(vdb_bruteforce** out, int metric, size_t dim, size_t capacity) {
+    return guarded([&] {
+        if (!out) throw std::invalid_argument("null output pointer");
+        if (metric != VDB_L2 && metric != VDB_IP) throw std::invalid_argument("unknown metric");
+        std::unique_ptr<vdb_bruteforce> bf(new vdb_bruteforce);
+        bf->host.reset(new HostBruteforce(metric, dim, capacity));
+        *out = bf.release();
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_bf_load(vdb_bruteforce** out, const char* path, int metric, size_t dim) {
+    return guarded([&] {
+        if (!out || !path) throw std::invalid_argument("null argument");
+        if (metric != VDB_L2 && metric != VDB_IP) throw std::invalid_argument("unknown metric");
+        std::unique_ptr<vdb_bruteforce> bf(new vdb_bruteforce);
+        bf->host.reset(new HostBruteforce(std::string(path), metric, dim));
+        *out = bf.release();
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_bf_save(const vdb_bruteforce* bf, const char* path) {
+    return guarded([&] {
+        if (!bf || !path) throw std::invalid_argument("null argument");
+        bf->host->save(path);
+        return (int)VDB_OK;
+    });
+}
+
+void vdb_bf_free(vdb_bruteforce* bf) { delete bf; }
+
+int vdb_bf_add_batch(vdb_bruteforce* bf, const float* vecs, const uint64_t* labels, size_t n) {
+    return guarded([&] {
+        if (!bf || (!vecs && n)) throw std::invalid_argument("null argument");
+        const size_t dim = bf->host->dim;
+        const size_t base = bf->host->count;
+        for (size_t i = 0; i < n; ++i) bf->host->add(vecs + i * dim, labels ? labels[i] : (uint64_t)(base + i));
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_bf_remove(vdb_bruteforce* bf, uint64_t label) {
+    return guarded([&] {
+        if (!bf) throw std::invalid_argument("null index");
+        bf->host->remove(label);
+        return (int)VDB_OK;
+    });
+}
+
+size_t vdb_bf_count(const vdb_bruteforce* bf) { return bf ? bf->host->count : 0; }
+
+int vdb_bf_to_device(vdb_bruteforce* bf, int device) {
+    return guarded([&] {
+        if (!bf) throw std::invalid_argument("null index");
+        upload_bf(bf, device);
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_bf_search_batch_device(const vdb_bruteforce* cbf, const float* d_queries, size_t nq, size_t k, int precision,
+                               float* d_out_dist, uint64_t* d_out_label, void* stream_) {
+    return guarded([&] {
+        vdb_bruteforce* bf = const_cast<vdb_bruteforce*>(cbf);
+        if (!bf) throw std::invalid_argument("null index");
+        if (bf->device < 0) throw DeviceError("index is not on a device: call vdb_bf_to_device first");
+        if (bf->device_version != bf->host->version) throw DeviceError("index changed since vdb_bf_to_device: upload it again");
+        if (nq == 0) return (int)VDB_OK;
+        if (!d_queries || !d_out_dist || !d_out_label) throw std::invalid_argument("null buffer");
+        if (k == 0) throw std::invalid_argument("k must be > 0");
+        if (nq > 0x7FFFFFFFull) throw std::invalid_argument("batch too large");
+        if (precision != VDB_BF_FP32) throw Unsupported("bf16 brute-force precisions are not implemented yet");
+        if (k > kBfMaxK) throw Unsupported("brute force: k above 1024 is not supported by the device path");
+        hipStream_t stream = (hipStream_t)stream_;
+        DeviceGuard guard(bf->device);
+        std::unique_lock<std::mutex> lock(bf->scratch_lock);
+        auto& ws = bf->scratch[stream];
+        if (!ws) ws.reset(new DevBuf);
+        const size_t need = bf_exact_workspace_bytes((uint32_t)nq);
+        if (ws->bytes < need) {
+            if (ws->p) VDB_HIP(hipStreamSynchronize(stream));
+            ws->alloc(need);
+        }
+        std::string err;
+        const int rc = launch_bf_exact((const float*)bf->vecs.p, (const uint64_t*)bf->labels.p, bf->n,
+                                       (uint32_t)bf->host->dim, bf->vstride, bf->host->metric, d_queries, (uint32_t)nq,
+                                       (uint32_t)k, d_out_dist, d_out_label, ws->p, stream, &err);
+        if (rc != 0) return set_error(rc, err);
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_bf_search_batch(const vdb_bruteforce* bf, const float* queries, size_t nq, size_t k, int precision,
+                        float* out_dist, uint64_t* out_label) {
+    return guarded([&] {
+        if (!bf) throw std::invalid_argument("null index");
+        if (bf->device < 0) throw DeviceError("index is not on a device: call vdb_bf_to_device first");
+        if (nq == 0) return (int)VDB_OK;
+        if (!queries || !out_dist || !out_label) throw std::invalid_argument("null buffer");
+        if (k == 0) throw std::invalid_argument("k must be > 0");
+        DeviceGuard guard(bf->device);
+        const size_t dim = bf->host->dim;
+        DevBuf dq, dd, dl;
+        dq.alloc(nq * dim * 4);
+        dd.alloc(nq * k * 4);
+        dl.alloc(nq * k * 8);
+        VDB_HIP(hipMemcpy(dq.p, queries, nq * dim * 4, hipMemcpyHostToDevice));
+        const int rc = vdb_bf_search_batch_device(bf, (const float*)dq.p, nq, k, precision, (float*)dd.p,
+                                                  (uint64_t*)dl.p, nullptr);
+        if (rc != VDB_OK) return rc;
+        VDB_HIP(hipStreamSynchronize(nullptr));
+        VDB_HIP(hipMemcpy(out_dist, dd.p, nq * k * 4, hipMemcpyDeviceToHost));
+        VDB_HIP(hipMemcpy(out_label, dl.p, nq * k * 8, hipMemcpyDeviceToHost));
+        return (int)VDB_OK;
+    });
+}
+
+// ---- shard merge ------------------------------------------------------------------------
+
+int vdb_merge_topk_device(const float* d_dist, const uint64_t* d_label, size_t n_lists, size_t nq, size_t k,
+                          float* d_out_dist, uint64_t* d_out_label, void* stream) {
+    return guarded([&] {
+        if (nq == 0 || k == 0) return (int)VDB_OK;
+        if (!d_dist || !d_label || !d_out_dist || !d_out_label) throw std::invalid_argument("null buffer");
+        if (n_lists == 0 || n_lists * k > 5461) throw std::invalid_argument("merge: n_lists * k must be in 1..5461");
+        std::string err;
+        const int rc = launch_merge_topk(d_dist, d_label, (uint32_t)n_lists, (uint32_t)nq, (uint32_t)k, d_out_dist,
+                                         d_out_label, (hipStream_t)stream, &err);
+        if (rc != 0) return set_error(rc, err);
+        return (int)VDB_OK;
+    });
+}
+
+}  // extern "C"

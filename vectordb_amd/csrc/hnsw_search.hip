@@ -1,0 +1,581 @@
+// hnsw_search.hip — gfx950 kernels for HierarchicalNSW::searchKnn.
+//
+// Reference path restated here (paths relative to the reference's src/hnsw/hnsw_scratch/):
+//   searchKnn                      hnsw_core.hpp:1107-1159
+//     upper-layer greedy descent   :1111-1138
+//     searchBaseLayerST<bare=true> called :1143-1147, defined nowhere; restated from the
+//                                  construction-time loop :293-356
+//     epilogue (trim to k, labels) :1150-1158 + SearchKNNCloserFirst hnswlib.hpp:87-99
+//   distances                      space_l2.hpp:1-14, space_ip.hpp:3-18 (summation order
+//                                  "tree64", DESIGN.md "Numerics")
+//   visited set                    visited_list_pool.hpp:36-58 -> exact hash set in LDS
+//
+// One wavefront (64 lanes) runs one query from entry point to output.
+//
+//  * Distances.  A 16-lane group scores one neighbour: lane t of the group owns the
+//    virtual lanes 4t..4t+3 of the tree64 order, i.e. elements 64j+4t..64j+4t+3 of the
+//    vector for every 64-element chunk j, fetched as one 16-byte load per chunk (16 lanes
+//    x 16 B = 256 contiguous bytes = two full 128-B lines).  A wave scores four
+//    neighbours per instruction stream and keeps the loads of up to 32 neighbours in
+//    flight before the first FMA.  The 64 partial sums are folded by the pairwise tree:
+//    two levels inside the lane, four DPP levels (xor 1, xor 2, half-mirror, mirror).
+//  * Result set and candidate set are ONE sorted array of 64-bit keys
+//    (ordered(dist) << 32 | id << 1 | expanded) striped over the lanes' registers, R
+//    registers per lane (capacity 64 R >= ef).  Inserting is a wave-wide shift by one lane
+//    (DPP wave_shr) - no heap.  The next candidate is the first key whose `expanded` bit is
+//    clear.  Why this equals the reference's two heaps, ties included: DESIGN.md
+//    "Traversal state".
+//  * Visited set: open-addressing hash of node ids in LDS, inserted with ds_cmpst
+//    (atomicCAS) so that "test and mark" of all neighbours of a node is one parallel step.
+//
+// Queries whose state outgrows the fast configuration (hash fill limit, or equal-distance
+// keys pushed off the end of the array) are appended to a work list and re-run by the
+// same kernel body in its exact large configuration (2R registers, visited bitmap in HBM).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <type_traits>
+
+#include "device_index.hpp"
+#include "launch.hpp"
+
+namespace vdb {
+
+namespace {
+
+constexpr uint32_t kEmptyWord = 0xFFFFFFFFu;
+
+// ------------------------------------------------------------------ lane primitives
+
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // lane i <- lane 7-i inside each 8
+constexpr int kDppMirror = 0x140;      // lane i <- lane 15-i inside each 16
+constexpr int kDppWaveShr1 = 0x138;    // lane i <- lane i-1 over the whole wave
+
+__device__ __forceinline__ uint32_t readlane(uint32_t v, int lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+__device__ __forceinline__ uint32_t bpermute(uint32_t v, int src_lane) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
+}
+__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// float bits -> unsigned with the same order (and back).  -0.0 never occurs (sums of
+// squares start from +0; 1 - x rounds to +0), NaN inputs are outside the contract.
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t u) {
+    return __builtin_bit_cast(float, (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int src = lane_id() ^ off;
+        const uint32_t lo = bpermute((uint32_t)v, src);
+        const uint32_t hi = bpermute((uint32_t)(v >> 32), src);
+        const uint64_t o = ((uint64_t)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------ distance engine
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// Scores up to 32 nodes.  In: lane r (< m) holds node id ids[r].  Out: lane r (< m) holds
+// the ordered-u32 distance of node r; other lanes 0xFFFFFFFF.
+// NCH = number of 64-float chunks per row that are touched; GPB = 16-lane groups whose
+// loads are issued before the first FMA (4 nodes each).
+template <int NCH, int GPB>
+__device__ __forceinline__ uint32_t score_nodes(const DevGraph& g, const f32x4 (&q)[NCH], uint32_t ids, uint32_t m,
+                                                int lane) {
+    const int grp = lane >> 4, t = lane & 15;
+    const uint32_t vstride = g.vstride;
+    const bool is_l2 = g.metric == 0;
+    uint32_t out = kEmptyWord;
+    const uint32_t ngroups = (m + 3u) >> 2;
+#pragma unroll 1
+    for (uint32_t base = 0; base < ngroups; base += GPB) {
+        f32x4 x[GPB][NCH];
+#pragma unroll
+        for (int b = 0; b < GPB; ++b) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) x[b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (base + b < ngroups) {  // wave-uniform
+                const uint32_t r = 4u * (base + b) + (uint32_t)grp;
+                const uint32_t nid = bpermute(ids, (int)(r & 63u));
+                if (r < m) {
+                    const float* row = g.vecs + (size_t)nid * vstride + 4 * t;
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j)
+                        if ((uint32_t)(64 * j + 4 * t) < vstride) x[b][j] = *reinterpret_cast<const f32x4*>(row + 64 * j);
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < GPB; ++b) {
+            if (base + b < ngroups) {  // wave-uniform
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                if (is_l2) {
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j) {
+                        const float d0 = q[j].x - x[b][j].x, d1 = q[j].y - x[b][j].y;
+                        const float d2 = q[j].z - x[b][j].z, d3 = q[j].w - x[b][j].w;
+                        a0 = __builtin_fmaf(d0, d0, a0);
+                        a1 = __builtin_fmaf(d1, d1, a1);
+                        a2 = __builtin_fmaf(d2, d2, a2);
+                        a3 = __builtin_fmaf(d3, d3, a3);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j) {
+                        a0 = __builtin_fmaf(q[j].x, x[b][j].x, a0);
+                        a1 = __builtin_fmaf(q[j].y, x[b][j].y, a1);
+                        a2 = __builtin_fmaf(q[j].z, x[b][j].z, a2);
+                        a3 = __builtin_fmaf(q[j].w, x[b][j].w, a3);
+                    }
+                }
+                // pairwise tree over the 64 virtual lanes: 2 levels in-lane, 4 across lanes
+                float s = (a0 + a1) + (a2 + a3);
+                s = s + dpp_f32<kDppXor1>(s);
+                s = s + dpp_f32<kDppXor2>(s);
+                s = s + dpp_f32<kDppHalfMirror>(s);
+                s = s + dpp_f32<kDppMirror>(s);
+                if (!is_l2) s = 1.0f - s;
+                // node r = 4(base+b)+g lives in group g; hand it to lane r
+                const uint32_t v = bpermute(f2ord(s), 16 * (lane & 3));
+                const uint32_t r = (uint32_t)lane;
+                if ((r >> 2) == base + b && r < m) out = v;
+            }
+        }
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------ visited set
+
+struct LdsVisited {
+    uint32_t* tab;
+    uint32_t hbits;
+    __device__ __forceinline__ void clear(int lane) {
+        const uint32_t n = 1u << hbits;
+        for (uint32_t i = lane * 4; i < n; i += 256) *reinterpret_cast<uint4*>(tab + i) = uint4{~0u, ~0u, ~0u, ~0u};
+    }
+    // true when `id` was not in the set (and inserts it)
+    __device__ __forceinline__ bool test_and_set(uint32_t id) {
+        const uint32_t mask = (1u << hbits) - 1u;
+        uint32_t s = (id * 0x9E3779B1u) >> (32u - hbits);
+        for (;;) {
+            const uint32_t old = atomicCAS(&tab[s], kEmptyWord, id);
+            if (old == kEmptyWord) return true;
+            if (old == id) return false;
+            s = (s + 1u) & mask;
+        }
+    }
+    __device__ __forceinline__ uint32_t limit() const { return (3u << hbits) >> 2; }  // 75 % fill
+};
+
+struct BitmapVisited {  // exact for any number of visited nodes; one n-bit map in HBM per resident wave
+    uint32_t* bits;
+    uint32_t words;
+    __device__ __forceinline__ void clear(int lane) {
+        for (uint32_t i = lane; i < words; i += 64) bits[i] = 0u;
+    }
+    __device__ __forceinline__ bool test_and_set(uint32_t id) {
+        const uint32_t bit = 1u << (id & 31u);
+        return (atomicOr(&bits[id >> 5], bit) & bit) == 0u;
+    }
+    __device__ __forceinline__ uint32_t limit() const { return 0xFFFFFFFFu; }
+};
+
+// ------------------------------------------------------------------ sorted key array
+
+// Entry i of the array lives in register i/64 of lane i%64.  EMPTY = all ones.
+template <int R>
+struct KeyArray {
+    uint32_t hi[R], lo[R];
+
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int r = 0; r < R; ++r) hi[r] = lo[r] = kEmptyWord;
+    }
+    __device__ __forceinline__ uint32_t hi_at(uint32_t idx) const {  // idx wave-uniform
+        uint32_t v = kEmptyWord;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if ((idx >> 6) == (uint32_t)r) v = readlane(hi[r], (int)(idx & 63u));
+        return v;
+    }
+    // Insert (khi, klo); keys are distinct.  Returns the key that fell off the end.
+    __device__ __forceinline__ void insert(uint32_t khi, uint32_t klo, int lane, uint32_t& off_hi, uint32_t& off_lo) {
+        off_hi = readlane(hi[R - 1], 63);
+        off_lo = readlane(lo[R - 1], 63);
+        uint32_t uh[R], ul[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uh[r] = dpp_u32<kDppWaveShr1>(0u, hi[r]);
+            ul[r] = dpp_u32<kDppWaveShr1>(0u, lo[r]);
+            if (r > 0) {
+                const uint32_t ph = readlane(hi[r - 1], 63), pl = readlane(lo[r - 1], 63);
+                if (lane == 0) {
+                    uh[r] = ph;
+                    ul[r] = pl;
+                }
+            }
+        }
+        const uint64_t key = ((uint64_t)khi << 32) | klo;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint64_t up = ((uint64_t)uh[r] << 32) | ul[r];
+            const uint64_t my = ((uint64_t)hi[r] << 32) | lo[r];
+            const uint64_t nv = up > key ? up : (my > key ? key : my);
+            hi[r] = (uint32_t)(nv >> 32);
+            lo[r] = (uint32_t)nv;
+        }
+    }
+    // Entries at index >= ef survive only while their distance equals the bound.
+    __device__ __forceinline__ void trim(uint32_t ef, uint32_t bound_hi, int lane) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t idx = (uint32_t)(r * 64 + lane);
+            if (idx >= ef && hi[r] != bound_hi) hi[r] = lo[r] = kEmptyWord;
+        }
+    }
+    // First key with the expanded bit clear: returns its node id and sets the bit.
+    __device__ __forceinline__ bool pop_candidate(int lane, uint32_t& id) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint64_t open = ballot((lo[r] & 1u) == 0u);
+            if (open) {
+                const int p = __builtin_ctzll(open);
+                id = readlane(lo[r], p) >> 1;
+                if (lane == p) lo[r] |= 1u;
+                return true;
+            }
+        }
+        return false;
+    }
+};
+
+// ------------------------------------------------------------------ the search
+
+struct SearchArgs {
+    DevGraph g;
+    const float* queries;  // [nq][dim]
+    uint32_t nq, k, ef, hbits;
+    float* out_dist;       // [nq][k]
+    uint64_t* out_label;   // [nq][k]
+    uint32_t* out_stats;   // nullable [nq][4]
+    uint32_t* redo;        // [0] = count, [1 + i] = query ids that must be re-run
+    uint32_t* bitmaps;     // large configuration: [gridDim.x][bitmap_words]
+    uint32_t bitmap_words;
+};
+
+template <int NCH, int GPB, int R, bool LARGE>
+__global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lane = lane_id();
+    const DevGraph& g = a.g;
+
+    typename std::conditional<LARGE, BitmapVisited, LdsVisited>::type vis;
+    if constexpr (LARGE) {
+        vis.bits = a.bitmaps + (size_t)blockIdx.x * a.bitmap_words;
+        vis.words = a.bitmap_words;
+    } else {
+        vis.tab = lds;
+        vis.hbits = a.hbits;
+    }
+
+    const uint32_t n_work = LARGE ? a.redo[0] : a.nq;
+#pragma unroll 1
+    for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const uint32_t qi = LARGE ? a.redo[1 + w] : w;
+        const uint32_t k = a.k, ef = a.ef;
+        float* od = a.out_dist + (size_t)qi * k;
+        uint64_t* ol = a.out_label + (size_t)qi * k;
+
+        uint32_t ndis = 0, hops0 = 0, hops_up = 0;
+        if (g.n == 0) {  // hnsw_core.hpp:1109
+            for (uint32_t i = lane; i < k; i += 64) {
+                od[i] = __builtin_inff();
+                ol[i] = ~0ull;
+            }
+            if (a.out_stats && lane == 0) {
+                uint32_t* st = a.out_stats + (size_t)qi * 4;
+                st[0] = st[1] = st[2] = st[3] = 0;
+            }
+            continue;
+        }
+
+        // the query, in the register layout of score_nodes (zero beyond dim)
+        f32x4 q[NCH];
+        {
+            const float* qp = a.queries + (size_t)qi * g.dim;
+            const int t = lane & 15;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                float e[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t pos = (uint32_t)(64 * j + 4 * t + c);
+                    e[c] = pos < g.dim ? qp[pos] : 0.f;
+                }
+                q[j] = f32x4{e[0], e[1], e[2], e[3]};
+            }
+        }
+
+        vis.clear(lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- entry point and greedy descent, hnsw_core.hpp:1111-1138
+        uint32_t cur = g.entry;
+        uint32_t cur_d = readlane(score_nodes<NCH, GPB>(g, q, cur, 1u, lane), 0);
+        ndis += 1;
+        for (int level = g.max_level; level > 0; --level) {
+            bool changed = true;
+            while (changed) {
+                changed = false;
+                const uint32_t row = g.upper_row[cur] + (uint32_t)(level - 1);
+                const uint32_t nb = (uint32_t)lane < g.ustride ? g.upper_links[(size_t)row * g.ustride + lane] : kNoId;
+                const uint32_t n = (uint32_t)__builtin_popcountll(ballot(nb != kNoId));
+                hops_up += 1;
+                ndis += n;
+                if (n == 0) break;
+                // all n distances are evaluated by the reference too; the scan keeps the
+                // first strict minimum below cur_d
+                const uint32_t d = score_nodes<NCH, GPB>(g, q, nb, n, lane);
+                const uint64_t best = wave_min_u64(((uint64_t)d << 32) | (uint32_t)lane);
+                const uint32_t bd = (uint32_t)(best >> 32);
+                if (bd < cur_d) {
+                    cur_d = bd;
+                    cur = readlane(nb, (int)(best & 63u));
+                    changed = true;
+                }
+            }
+        }
+
+        // ---- layer 0: searchBaseLayerST<bare> (restated from hnsw_core.hpp:293-356)
+        KeyArray<R> arr;
+        arr.clear();
+        if (lane == 0) {
+            arr.hi[0] = cur_d;
+            arr.lo[0] = cur << 1;
+        }
+        uint32_t bound = ef > 1 ? kEmptyWord : cur_d;  // hi of entry ef-1
+        uint32_t nvis = 1;
+        bool overflow = false;
+        if (lane == 0) (void)vis.test_and_set(cur);
+
+        uint32_t cand;
+#pragma unroll 1
+        while (arr.pop_candidate(lane, cand)) {
+            hops0 += 1;
+            if (nvis + g.l0stride > vis.limit()) {
+                overflow = true;
+                break;
+            }
+            const uint32_t nb = (uint32_t)lane < g.l0stride ? g.links0[(size_t)cand * g.l0stride + lane] : kNoId;
+            const bool fresh = nb != kNoId && vis.test_and_set(nb);
+            const uint64_t fm = ballot(fresh);
+            const uint32_t m_all = (uint32_t)__builtin_popcountll(fm);
+            if (m_all == 0) continue;
+            nvis += m_all;
+            ndis += m_all;
+            // compact the unvisited neighbours to lanes 0..m-1, list order kept: a full
+            // permutation (fresh lanes to their rank, the others behind them) so that no
+            // two lanes of the forward permute write the same destination
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+            const uint32_t dest = fresh ? rank : m_all + ((uint32_t)lane - rank);
+            const uint32_t ids_c = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)(fresh ? nb : kNoId));
+
+#pragma unroll 1
+            for (uint32_t c0 = 0; c0 < m_all; c0 += 32) {
+                const uint32_t m = m_all - c0 < 32u ? m_all - c0 : 32u;
+                const uint32_t ids_part = c0 == 0 ? ids_c : bpermute(ids_c, (lane + 32) & 63);
+                const uint32_t dord = score_nodes<NCH, GPB>(g, q, ids_part, m, lane);
+                // sequential admission in list order with the evolving bound, :339-349
+                uint64_t pend = ballot(dord < bound);
+                while (pend) {
+                    const int r = __builtin_ctzll(pend);
+                    pend &= pend - 1;
+                    const uint32_t d = readlane(dord, r);
+                    if (d < bound) {
+                        const uint32_t id = readlane(ids_part, r);
+                        uint32_t off_hi, off_lo;
+                        arr.insert(d, id << 1, lane, off_hi, off_lo);
+                        bound = arr.hi_at(ef - 1);
+                        if (off_hi != kEmptyWord && off_hi == bound && (off_lo & 1u) == 0u) overflow = true;
+                        arr.trim(ef, bound, lane);
+                        pend &= ballot(dord < bound);
+                    }
+                }
+            }
+            if (overflow) break;
+        }
+
+        if (overflow) {
+            if constexpr (!LARGE) {
+                if (lane == 0) {
+                    const uint32_t slot = atomicAdd(&a.redo[0], 1u);
+                    a.redo[1 + slot] = qi;
+                }
+                continue;
+            }
+        }
+
+        // ---- epilogue, hnsw_core.hpp:1150-1158 + hnswlib.hpp:87-99
+        // results = entries 0..min(size, ef)-1; keep the k smallest, order by (dist, label)
+        uint32_t size = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t idx = (uint32_t)(r * 64 + lane);
+            size += (uint32_t)__builtin_popcountll(ballot(idx < ef && !(arr.hi[r] == kEmptyWord && arr.lo[r] == kEmptyWord)));
+        }
+        const uint32_t kout = size < k ? size : k;
+        // stage (ord dist, label) in LDS, then every entry finds its rank among ties
+        __builtin_amdgcn_wave_barrier();
+        uint32_t* s_hi = lds;                                        // [64 R]
+        uint64_t* s_lab = reinterpret_cast<uint64_t*>(lds + 64 * R);  // [64 R]
+        bool tie = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t idx = (uint32_t)(r * 64 + lane);
+            uint64_t lab = 0;
+            if (idx < kout) lab = g.labels[arr.lo[r] >> 1];
+            s_hi[idx] = arr.hi[r];
+            s_lab[idx] = lab;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t idx = (uint32_t)(r * 64 + lane);
+            if (idx > 0 && idx < kout && s_hi[idx - 1] == arr.hi[r]) tie = true;
+        }
+        const bool any_tie = ballot(tie) != 0ull;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t idx = (uint32_t)(r * 64 + lane);
+            if (idx < kout) {
+                uint32_t pos = idx;
+                const uint64_t lab = s_lab[idx];
+                if (any_tie) {
+                    pos = 0;
+                    for (uint32_t j = 0; j < kout; ++j) {
+                        const uint32_t oh = s_hi[j];
+                        const uint64_t olab = s_lab[j];
+                        pos += (oh < arr.hi[r] || (oh == arr.hi[r] && olab < lab)) ? 1u : 0u;
+                    }
+                }
+                od[pos] = ord2f(arr.hi[r]);
+                ol[pos] = lab;
+            }
+        }
+        for (uint32_t i = kout + lane; i < k; i += 64) {
+            od[i] = __builtin_inff();
+            ol[i] = ~0ull;
+        }
+        if (a.out_stats && lane == 0) {
+            uint32_t* st = a.out_stats + (size_t)qi * 4;
+            st[kStatNdis] = ndis;
+            st[kStatHops0] = hops0;
+            st[kStatHopsUpper] = hops_up;
+            st[kStatFound] = kout;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------ launch
+
+template <int NCH, int GPB, int R>
+int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
+    const size_t epilogue_bytes = (size_t)64 * R * 12;
+    size_t lds_small = (size_t)4 << a.hbits;
+    if (lds_small < epilogue_bytes) lds_small = epilogue_bytes;
+    hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, false>), dim3(a.nq), dim3(64), lds_small, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) {
+        const uint32_t blocks = a.nq < kLargeBlocks ? a.nq : kLargeBlocks;
+        hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, 2 * R, true>), dim3(blocks), dim3(64), (size_t)64 * 2 * R * 12,
+                           stream, a);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        if (err) *err = std::string("hnsw_search launch failed: ") + hipGetErrorString(e);
+        return 3;
+    }
+    return 0;
+}
+
+template <int NCH, int GPB>
+int launch_r(const SearchArgs& a, hipStream_t stream, std::string* err) {
+    if (a.ef <= 64) return launch_cfg<NCH, GPB, 1>(a, stream, err);
+    if (a.ef <= 128) return launch_cfg<NCH, GPB, 2>(a, stream, err);
+    return launch_cfg<NCH, GPB, 4>(a, stream, err);
+}
+
+}  // namespace
+
+int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, uint32_t k, uint32_t ef,
+                       float* d_out_dist, uint64_t* d_out_label, uint32_t* d_out_stats, const HnswSearchWork& work,
+                       hipStream_t stream, std::string* err) {
+    if (nq == 0) return 0;
+    auto unsupported = [&](const char* what) {
+        if (err) *err = what;
+        return 4;
+    };
+    if (ef == 0 || ef > kMaxEf) return unsupported("ef (= max(efSearch, k)) above 256 is not supported by the device path");
+    if (g.vstride > kMaxVecStride) return unsupported("dim above 1024 is not supported by the device path");
+    if (g.l0stride > kMaxL0Stride || g.ustride > kMaxL0Stride) return unsupported("M above 32 is not supported by the device path");
+    if (!work.redo || (g.n && (!work.bitmaps || work.bitmap_words < (g.n + 31u) / 32u))) {
+        if (err) *err = "hnsw_search: workspace missing";
+        return 1;
+    }
+    SearchArgs a;
+    a.g = g;
+    a.queries = d_queries;
+    a.nq = nq;
+    a.k = k;
+    a.ef = ef;
+    uint32_t need = (uint32_t)(((uint64_t)ef * g.l0stride * 4u + 2u) / 3u), hb = 10;
+    while ((1u << hb) < need && hb < 14) ++hb;
+    a.hbits = hb;
+    a.out_dist = d_out_dist;
+    a.out_label = d_out_label;
+    a.out_stats = d_out_stats;
+    a.redo = work.redo;
+    a.bitmaps = work.bitmaps;
+    a.bitmap_words = work.bitmap_words;
+    hipError_t e = hipMemsetAsync(work.redo, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) {
+        if (err) *err = std::string("hipMemsetAsync: ") + hipGetErrorString(e);
+        return 3;
+    }
+    const uint32_t nch = (g.vstride + 63u) / 64u;
+    if (nch <= 1) return launch_r<1, 8>(a, stream, err);
+    if (nch <= 2) return launch_r<2, 8>(a, stream, err);
+    if (nch <= 4) return launch_r<4, 4>(a, stream, err);
+    if (nch <= 8) return launch_r<8, 2>(a, stream, err);
+    return launch_r<16, 1>(a, stream, err);
+}
+
+}  // namespace vdb

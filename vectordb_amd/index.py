@@ -1,0 +1,287 @@
+"""Host-side mirror of the reference's index interface over the C-ABI.
+
+Mirrors ``AlgorithmInterface<float>`` (reference src/hnsw/hnsw_scratch/hnswlib.hpp:71-85)
+and the public surface of ``HierarchicalNSW`` (hnsw_core.hpp:21, :110-123, :207-256, :709-782,
+:1107) and ``BruteforceSearch`` (bruteforce.hpp:14): same method names, argument meaning and
+error behaviour (the reference throws std::runtime_error; here ``VdbError``).  The batched
+entry points are the real ones — a single-query ``searchKnn`` is a batch of one.
+
+Graph building runs on the host with the reference's algorithm; every search runs the
+gfx950 kernels through ``libvdb_amd.so``.  Nothing here computes a distance on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BF_BF16, BF_BF16_RERANK, BF_FP32, IP, L2, SUM_SEQ, SUM_TREE64, VdbError, check  # noqa: F401
+
+_f32p = C.POINTER(C.c_float)
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+
+
+def _as_f32(a, dim: int) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim == 1:
+        a = a.reshape(1, -1)
+    if a.ndim != 2 or a.shape[1] != dim:
+        raise ValueError(f"expected [n, {dim}] float32, got {a.shape}")
+    return a
+
+
+def _is_torch_cuda(x) -> bool:
+    return hasattr(x, "is_cuda") and bool(x.is_cuda)
+
+
+class _Space:
+    """SpaceInterface (hnswlib.hpp:54-61): data size and dimension of the float space."""
+
+    metric = L2
+
+    def __init__(self, dim: int):
+        self.dim = int(dim)
+
+    def get_data_size(self) -> int:
+        return self.dim * 4
+
+    def get_dim(self) -> int:
+        return self.dim
+
+
+class L2Space(_Space):  # space_l2.hpp:16-37
+    metric = L2
+
+
+class InnerProductSpace(_Space):  # space_ip.hpp:20-41
+    metric = IP
+
+
+class HierarchicalNSW:
+    """HierarchicalNSW<float> (hnsw_core.hpp:21)."""
+
+    def __init__(self, space: _Space, capacity: int = 0, M: int = 16, ef_construction: int = 200,
+                 random_seed: int = 100, reuse_deleted: bool = False, *, location: str | None = None):
+        if reuse_deleted:
+            raise VdbError(_lib.VDB_ERR_UNSUPPORTED, "reuse_deleted is not implemented")
+        self._l = _lib.lib()
+        self.space = space
+        self._h = C.c_void_p()
+        if location is not None:  # load ctor, hnsw_core.hpp:110-116
+            check(self._l.vdb_index_load(C.byref(self._h), location.encode(), space.metric, space.dim, capacity))
+        else:
+            check(self._l.vdb_index_create(C.byref(self._h), space.metric, space.dim, capacity, M, ef_construction,
+                                           random_seed))
+        self._device = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._l.vdb_index_free(h)
+            self._h = None
+
+    # ---- building (host, reference algorithm) -------------------------------------
+    def addPoint(self, datapoint, label: int, replace_deleted: bool = False) -> None:
+        if replace_deleted:
+            raise VdbError(_lib.VDB_ERR_RUNTIME, "Replacement of deleted elements is disabled in constructor")
+        v = _as_f32(datapoint, self.space.dim)
+        check(self._l.vdb_index_add(self._h, v.ctypes.data_as(_f32p), int(label), -1))
+
+    def add_items(self, vecs, labels=None, n_threads: int = 1) -> None:
+        v = _as_f32(vecs, self.space.dim)
+        lp = None
+        if labels is not None:
+            labels = np.ascontiguousarray(labels, dtype=np.uint64)
+            if labels.shape != (v.shape[0],):
+                raise ValueError("labels must be [n]")
+            lp = labels.ctypes.data_as(_u64p)
+        check(self._l.vdb_index_add_batch(self._h, v.ctypes.data_as(_f32p), lp, v.shape[0], n_threads))
+
+    def set_build_sum_order(self, order: int) -> None:
+        check(self._l.vdb_index_set_build_sum_order(self._h, order))
+
+    def saveIndex(self, location: str) -> None:
+        check(self._l.vdb_index_save(self._h, location.encode()))
+
+    def setefSearch(self, ef: int) -> None:
+        check(self._l.vdb_index_set_ef(self._h, ef))
+
+    def markDelete(self, label: int) -> None:
+        check(self._l.vdb_index_mark_delete(self._h, label))
+
+    def unmarkDelete(self, label: int) -> None:
+        check(self._l.vdb_index_unmark_delete(self._h, label))
+
+    def resizeIndex(self, new_capacity: int) -> None:
+        check(self._l.vdb_index_resize(self._h, new_capacity))
+
+    def checkIntegrity(self):
+        mn, mx = C.c_int(0), C.c_int(0)
+        rc = self._l.vdb_index_check_integrity(self._h, C.byref(mn), C.byref(mx))
+        return rc, mn.value, mx.value
+
+    def getCapacity(self) -> int:
+        return self._l.vdb_index_capacity(self._h)
+
+    def getElementCount(self) -> int:
+        return self._l.vdb_index_count(self._h)
+
+    def getDeletedCount(self) -> int:
+        return self._l.vdb_index_deleted_count(self._h)
+
+    max_level = property(lambda s: s._l.vdb_index_max_level(s._h))
+    entry = property(lambda s: s._l.vdb_index_entry(s._h))
+    ef = property(lambda s: s._l.vdb_index_ef(s._h))
+    M = property(lambda s: s._l.vdb_index_M(s._h))
+
+    def level_of(self, i: int) -> int:
+        return self._l.vdb_index_level_of(self._h, i)
+
+    def links(self, i: int, level: int) -> list[int]:
+        buf = (C.c_uint32 * 256)()
+        n = self._l.vdb_index_links(self._h, i, level, buf, 256)
+        return list(buf[:max(n, 0)])
+
+    # ---- device ---------------------------------------------------------------------
+    def to_device(self, device: int = 0) -> "HierarchicalNSW":
+        check(self._l.vdb_index_to_device(self._h, device))
+        self._device = device
+        return self
+
+    def device_bytes(self) -> int:
+        return self._l.vdb_index_device_bytes(self._h)
+
+    # ---- searching (gfx950 kernels) ----------------------------------------------
+    def search_batch(self, queries, k: int, stats: bool = False):
+        """SearchKNNCloserFirst for every row of `queries`.
+
+        numpy in -> numpy out (PCIe-inclusive); torch CUDA tensor in -> torch CUDA tensors
+        out, enqueued on torch's current stream with no host synchronisation.
+        Returns (dist [nq,k] f32 ascending, label [nq,k] u64/int64) and, with ``stats``,
+        a [nq,4] uint32 array {ndis, hops layer 0, hops upper, found}.
+        """
+        if _is_torch_cuda(queries):
+            import torch
+
+            q = queries.contiguous()
+            if q.dtype != torch.float32 or q.dim() != 2 or q.shape[1] != self.space.dim:
+                raise ValueError(f"expected [nq, {self.space.dim}] float32 CUDA tensor")
+            nq = q.shape[0]
+            dist = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+            label = torch.empty((nq, k), dtype=torch.int64, device=q.device)  # same bits as u64
+            st = torch.empty((nq, 4), dtype=torch.int32, device=q.device) if stats else None
+            stream = torch.cuda.current_stream(q.device).cuda_stream
+            check(self._l.vdb_search_batch_device(self._h, q.data_ptr(), nq, k, dist.data_ptr(), label.data_ptr(),
+                                                  st.data_ptr() if stats else None, stream))
+            return (dist, label, st) if stats else (dist, label)
+        q = _as_f32(queries, self.space.dim)
+        nq = q.shape[0]
+        dist = np.empty((nq, k), np.float32)
+        label = np.empty((nq, k), np.uint64)
+        st = np.empty((nq, 4), np.uint32) if stats else None
+        check(self._l.vdb_search_batch(self._h, q.ctypes.data_as(_f32p), nq, k, dist.ctypes.data_as(_f32p),
+                                       label.ctypes.data_as(_u64p), st.ctypes.data_as(_u32p) if stats else None))
+        return (dist, label, st) if stats else (dist, label)
+
+    def SearchKNNCloserFirst(self, query, k: int, filter=None):  # hnswlib.hpp:87-99
+        if filter is not None:
+            raise VdbError(_lib.VDB_ERR_UNSUPPORTED, "filtered search is not on the device path yet")
+        d, l = self.search_batch(np.asarray(query, np.float32).reshape(1, -1), k)
+        keep = l[0] != np.uint64(0xFFFFFFFFFFFFFFFF)
+        return [(float(a), int(b)) for a, b in zip(d[0][keep], l[0][keep])]
+
+    def searchKnn(self, query, k: int, filter=None):  # hnsw_core.hpp:1107; farthest first, like draining the heap
+        return list(reversed(self.SearchKNNCloserFirst(query, k, filter)))
+
+    SearchKNN = searchKnn  # the interface's spelling, hnswlib.hpp:75
+
+
+class BruteforceSearch:
+    """BruteforceSearch<float> (bruteforce.hpp:14)."""
+
+    def __init__(self, space: _Space, capacity: int = 0, *, location: str | None = None):
+        self._l = _lib.lib()
+        self.space = space
+        self._h = C.c_void_p()
+        if location is not None:
+            check(self._l.vdb_bf_load(C.byref(self._h), location.encode(), space.metric, space.dim))
+        else:
+            check(self._l.vdb_bf_create(C.byref(self._h), space.metric, space.dim, capacity))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._l.vdb_bf_free(h)
+            self._h = None
+
+    def addPoint(self, datapoint, label: int, replace_deleted: bool = False) -> None:
+        self.add_items(np.asarray(datapoint, np.float32).reshape(1, -1), np.array([label], np.uint64))
+
+    def add_items(self, vecs, labels=None) -> None:
+        v = _as_f32(vecs, self.space.dim)
+        lp = None
+        if labels is not None:
+            labels = np.ascontiguousarray(labels, dtype=np.uint64)
+            lp = labels.ctypes.data_as(_u64p)
+        check(self._l.vdb_bf_add_batch(self._h, v.ctypes.data_as(_f32p), lp, v.shape[0]))
+
+    def removePoint(self, label: int) -> None:
+        check(self._l.vdb_bf_remove(self._h, label))
+
+    def saveIndex(self, location: str) -> None:
+        check(self._l.vdb_bf_save(self._h, location.encode()))
+
+    def getElementCount(self) -> int:
+        return self._l.vdb_bf_count(self._h)
+
+    def to_device(self, device: int = 0) -> "BruteforceSearch":
+        check(self._l.vdb_bf_to_device(self._h, device))
+        return self
+
+    def search_batch(self, queries, k: int, precision: int = BF_FP32):
+        if _is_torch_cuda(queries):
+            import torch
+
+            q = queries.contiguous()
+            nq = q.shape[0]
+            dist = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+            label = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            stream = torch.cuda.current_stream(q.device).cuda_stream
+            check(self._l.vdb_bf_search_batch_device(self._h, q.data_ptr(), nq, k, precision, dist.data_ptr(),
+                                                     label.data_ptr(), stream))
+            return dist, label
+        q = _as_f32(queries, self.space.dim)
+        nq = q.shape[0]
+        dist = np.empty((nq, k), np.float32)
+        label = np.empty((nq, k), np.uint64)
+        check(self._l.vdb_bf_search_batch(self._h, q.ctypes.data_as(_f32p), nq, k, precision,
+                                          dist.ctypes.data_as(_f32p), label.ctypes.data_as(_u64p)))
+        return dist, label
+
+    def SearchKNNCloserFirst(self, query, k: int, filter=None):
+        if filter is not None:
+            raise VdbError(_lib.VDB_ERR_UNSUPPORTED, "filtered search is not on the device path yet")
+        d, l = self.search_batch(np.asarray(query, np.float32).reshape(1, -1), k)
+        keep = l[0] != np.uint64(0xFFFFFFFFFFFFFFFF)
+        return [(float(a), int(b)) for a, b in zip(d[0][keep], l[0][keep])]
+
+    def SearchKNN(self, query, k: int, filter=None):
+        return list(reversed(self.SearchKNNCloserFirst(query, k, filter)))
+
+
+def merge_topk(dist, label, k: int | None = None):
+    """Merge per-shard result lists [G, nq, k] (torch CUDA tensors) into [nq, k] on the device."""
+    import torch
+
+    G, nq, kk = dist.shape
+    k = kk if k is None else k
+    dist = dist.contiguous()
+    label = label.contiguous()
+    od = torch.empty((nq, k), dtype=torch.float32, device=dist.device)
+    ol = torch.empty((nq, k), dtype=torch.int64, device=dist.device)
+    stream = torch.cuda.current_stream(dist.device).cuda_stream
+    check(_lib.lib().vdb_merge_topk_device(dist.data_ptr(), label.data_ptr(), G, nq, kk, od.data_ptr(), ol.data_ptr(),
+                                           stream))
+    return od, ol
