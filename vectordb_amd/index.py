@@ -271,17 +271,17 @@ class BruteforceSearch:
         return list(reversed(self.SearchKNNCloserFirst(query, k, filter)))
 
 
-def merge_topk(dist, label, k: int | None = None):
-    """Merge per-shard result lists [G, nq, k] (torch CUDA tensors) into [nq, k] on the device."""
+def merge_topk(dist, label):
+    """Merge per-shard result lists [G, nq, k] (torch CUDA tensors, each row ascending) into the
+    k smallest (dist, label) per query, [nq, k], on the device (vdb_merge_topk_device)."""
     import torch
 
-    G, nq, kk = dist.shape
-    k = kk if k is None else k
+    G, nq, k = dist.shape
     dist = dist.contiguous()
     label = label.contiguous()
     od = torch.empty((nq, k), dtype=torch.float32, device=dist.device)
     ol = torch.empty((nq, k), dtype=torch.int64, device=dist.device)
     stream = torch.cuda.current_stream(dist.device).cuda_stream
-    check(_lib.lib().vdb_merge_topk_device(dist.data_ptr(), label.data_ptr(), G, nq, kk, od.data_ptr(), ol.data_ptr(),
+    check(_lib.lib().vdb_merge_topk_device(dist.data_ptr(), label.data_ptr(), G, nq, k, od.data_ptr(), ol.data_ptr(),
                                            stream))
     return od, ol
