@@ -168,21 +168,15 @@ def main() -> None:
     # ---- sharded variant (north star): base split over ranks + RCCL all-gather + merge --
     sharded = None
     if world > 1 and not args.no_sharded:
+        from vectordb_amd import sharding
         per = (args.n + world - 1) // world
-        lo, hi = rank * per, min(args.n, (rank + 1) * per)
-        hs = vi.HierarchicalNSW(vi.L2Space(args.dim), hi - lo, args.M, args.efc, 100 + rank)
-        hs.add_items(base[lo:hi], np.arange(lo, hi, dtype=np.uint64), n_threads=threads)
+        hs = sharding.build_shard(base, world, rank, vi.L2, args.M, args.efc, n_threads=threads)
         hs.to_device(local_rank)
         hs.setefSearch(chosen)
         shared_q = torch.from_numpy(law.sample(args.nq, seed=2)).to(dev)   # the SAME batch on every rank
 
         def sharded_step():
-            d, l = hs.search_batch(shared_q, args.k)
-            gd = torch.empty((world,) + tuple(d.shape), dtype=d.dtype, device=dev)
-            gl = torch.empty((world,) + tuple(l.shape), dtype=l.dtype, device=dev)
-            dist.all_gather_into_tensor(gd, d)
-            dist.all_gather_into_tensor(gl, l)
-            return vi.merge_topk(gd, gl)
+            return sharding.sharded_search(hs, shared_q, args.k)
 
         md, ml = sharded_step()
         torch.cuda.synchronize()

@@ -1,0 +1,108 @@
+"""Host side of the product (graph building in the reference's byte layout, persistence,
+maintenance calls, error behaviour) — everything except the device search."""
+import numpy as np
+import pytest
+
+from vectordb_amd import index as vi
+
+
+def rand(n, d, seed):
+    return np.random.default_rng(seed).random((n, d), dtype=np.float32)
+
+
+@pytest.mark.parametrize("dim,M,metric", [(5, 4, vi.L2), (33, 6, vi.IP), (70, 8, vi.L2), (130, 16, vi.IP)])
+def test_builder_equals_oracle_on_ragged_dims(orc, tmp_path, dim, M, metric):
+    """The AVX2 tree64 distance of the builder, the scalar tree64 of the oracle and (on the
+    GPU tests) the kernels are one function: same graph bytes for dims that exercise the
+    masked tail."""
+    x = rand(400, dim, dim)
+    space = vi.L2Space(dim) if metric == vi.L2 else vi.InnerProductSpace(dim)
+    h = vi.HierarchicalNSW(space, 400, M, 40, 100)
+    h.add_items(x)
+    h.saveIndex(str(tmp_path / "h.bin"))
+    o = orc.OracleHNSW(metric, dim, 400, M, 40, 100, mode=orc.TREE64)
+    o.add(x)
+    o.save(str(tmp_path / "o.bin"))
+    assert open(tmp_path / "h.bin", "rb").read() == open(tmp_path / "o.bin", "rb").read()
+
+
+def test_errors_match_reference_behaviour():
+    h = vi.HierarchicalNSW(vi.L2Space(8), 5, 4, 8)
+    x = rand(6, 8, 1)
+    for i in range(5):
+        h.addPoint(x[i], 100 + i)
+    with pytest.raises(vi.VdbError, match="exceeds the specified limit"):   # hnsw_core.hpp:1019
+        h.addPoint(x[5], 200)
+    with pytest.raises(vi.VdbError, match="Label not found"):               # :718
+        h.markDelete(999)
+    h.markDelete(101)
+    assert h.getDeletedCount() == 1
+    with pytest.raises(vi.VdbError, match="already deleted"):               # :734
+        h.markDelete(101)
+    h.unmarkDelete(101)
+    with pytest.raises(vi.VdbError, match="not deleted"):                   # :777
+        h.unmarkDelete(101)
+    with pytest.raises(vi.VdbError, match="Cannot resize"):                 # :503
+        h.resizeIndex(3)
+    h.resizeIndex(6)
+    h.addPoint(x[5], 200)
+    assert (h.getCapacity(), h.getElementCount()) == (6, 6)
+    with pytest.raises(vi.VdbError, match="Cannot open file"):              # :585
+        vi.HierarchicalNSW(vi.L2Space(8), location="/nonexistent/index.bin")
+    with pytest.raises(vi.VdbError):
+        vi.HierarchicalNSW(vi.L2Space(0), 5)
+    with pytest.raises(ValueError):
+        h.addPoint(np.zeros(9, np.float32), 1)
+
+
+def test_corrupt_file_is_rejected(tmp_path):
+    h = vi.HierarchicalNSW(vi.L2Space(8), 50, 4, 16)
+    h.add_items(rand(50, 8, 2))
+    p = tmp_path / "i.bin"
+    h.saveIndex(str(p))
+    raw = p.read_bytes()
+    (tmp_path / "short.bin").write_bytes(raw[:-7])
+    with pytest.raises(vi.VdbError, match="corrupted"):                     # :622-633
+        vi.HierarchicalNSW(vi.L2Space(8), location=str(tmp_path / "short.bin"))
+    with pytest.raises(vi.VdbError, match="layout"):
+        vi.HierarchicalNSW(vi.L2Space(12), location=str(p))
+    h2 = vi.HierarchicalNSW(vi.L2Space(8), location=str(p), capacity=80)
+    assert h2.getCapacity() == 80 and h2.getElementCount() == 50 and h2.ef == 10   # :655
+    h2.addPoint(rand(1, 8, 3)[0], 1000)
+    assert h2.getElementCount() == 51
+
+
+def test_parallel_build_integrity_and_levels():
+    x = rand(4000, 32, 9)
+    h = vi.HierarchicalNSW(vi.L2Space(32), 4000, 16, 100)
+    h.add_items(x, n_threads=8)
+    rc, lo, hi = h.checkIntegrity()
+    assert rc == 0 and lo >= 1
+    levels = np.array([h.level_of(i) for i in range(4000)])
+    # level ~ floor(-ln U / ln M): P(level >= 1) = 1/M (hnsw_core.hpp:177, :240-244 as intended)
+    assert 0.03 < (levels >= 1).mean() < 0.10
+    assert h.max_level == levels.max() and h.level_of(h.entry) == h.max_level
+    for i in (0, 17, 3999):
+        assert len(h.links(i, 0)) <= 32
+        for l in range(1, levels[i] + 1):
+            assert len(h.links(i, l)) <= 16
+
+
+def test_bruteforce_host_semantics(orc, tmp_path):
+    x = rand(20, 6, 4)
+    b = vi.BruteforceSearch(vi.L2Space(6), 20)
+    b.add_items(x[:10], np.arange(50, 60, dtype=np.uint64))
+    b.addPoint(x[10], 55)            # same label: overwritten in place, bruteforce.hpp:90-93
+    assert b.getElementCount() == 10
+    b.removePoint(52)                # last row moves into the hole, :119-138
+    assert b.getElementCount() == 9
+    b.removePoint(12345)             # unknown label: no-op
+    b.saveIndex(str(tmp_path / "b.bin"))
+    o = orc.OracleBruteforce(orc.L2, 6, path=str(tmp_path / "b.bin"), mode=orc.SEQ)
+    assert o.count == 9
+    r = o.search(x[10:11], 3)
+    assert r["label"][0, 0] == 55 and r["dist"][0, 0] == 0
+    b2 = vi.BruteforceSearch(vi.L2Space(6), location=str(tmp_path / "b.bin"))
+    assert b2.getElementCount() == 9
+    with pytest.raises(vi.VdbError, match="exceeds"):
+        b2.add_items(rand(20, 6, 5), np.arange(1000, 1020, dtype=np.uint64))
