@@ -1,0 +1,51 @@
+// Drives vectordb_amd/cpp/vdb_hnsw.hpp the way a user of the reference's C++ interface would.
+// argv[1] = "host": no GPU needed (build, save, load, error behaviour);
+// argv[1] = "gpu":  also searches and prints "label dist" lines for the pytest to compare.
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+#include "../vectordb_amd/cpp/vdb_hnsw.hpp"
+
+using namespace vdb_amd;
+
+int main(int argc, char** argv) {
+    const bool gpu = argc > 1 && !std::strcmp(argv[1], "gpu");
+    const std::string path = argc > 2 ? argv[2] : "/tmp/vdb_cpp_demo.bin";
+    const size_t n = 500, dim = 24;
+    std::mt19937 rng(42);
+    std::uniform_real_distribution<float> u(0.f, 1.f);
+    std::vector<float> x(n * dim);
+    for (auto& v : x) v = u(rng);
+
+    L2Space space(dim);
+    AlgorithmInterface<float>* alg = new HierarchicalNSW(&space, n, 8, 64);
+    for (size_t i = 0; i < n; ++i) alg->addPoint(x.data() + i * dim, i);
+    bool threw = false;
+    try {
+        alg->addPoint(x.data(), n + 1);  // hnsw_core.hpp:1019
+    } catch (const std::runtime_error& e) {
+        threw = std::strstr(e.what(), "exceeds the specified limit") != nullptr;
+    }
+    if (!threw) return 2;
+    alg->saveIndex(path);
+    delete alg;
+
+    HierarchicalNSW loaded(&space, path);
+    if (loaded.getElementCount() != n) return 3;
+    loaded.setefSearch(40);
+    if (!gpu) {
+        try {
+            loaded.searchKnn(x.data(), 5);
+            return 4;  // must not succeed without a device: there is no CPU fallback
+        } catch (const std::runtime_error&) {
+        }
+        std::puts("host ok");
+        return 0;
+    }
+    for (size_t q = 0; q < 10; ++q) {
+        auto res = loaded.SearchKNNCloserFirst(x.data() + q * dim, 5);
+        for (auto& p : res) std::printf("%zu %a\n", p.second, p.first);
+    }
+    return 0;
+}

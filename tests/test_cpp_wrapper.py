@@ -1,0 +1,45 @@
+"""The C++ mirror of the reference interface (vectordb_amd/cpp/vdb_hnsw.hpp) compiled with g++
+against the C-ABI library, as a maintainer of the reference would use it."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from vectordb_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def demo(tmp_path_factory):
+    out = tmp_path_factory.mktemp("cpp") / "demo"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp_wrapper_demo.cpp"), "-o", str(out),
+                           f"-L{libdir}", "-lvdb_amd", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    return str(out)
+
+
+@pytest.mark.skipif(_lib.lib().vdb_device_count() > 0, reason="box has a GPU")
+def test_cpp_wrapper_host_side(demo, tmp_path):
+    r = subprocess.run([demo, "host", str(tmp_path / "i.bin")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "host ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_wrapper_search_matches_oracle(demo, orc, tmp_path):
+    path = str(tmp_path / "i.bin")
+    r = subprocess.run([demo, "gpu", path], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = [(int(a), float.fromhex(b)) for a, b in (line.split() for line in r.stdout.strip().splitlines())]
+    o = orc.OracleHNSW.load(path, orc.L2, 24, mode=orc.TREE64)
+    o.set_ef(40)
+    # the demo's queries are its first 10 base vectors: read them back from the saved index
+    raw = np.fromfile(path, np.uint8)
+    stride = 16 * 4 + 4 + 24 * 4 + 8
+    rows = raw[96:96 + 500 * stride].reshape(500, stride)
+    x = rows[:, 68:68 + 96].copy().view(np.float32)
+    res = o.search(x[:10], 5)
+    want = [(int(l), float(d)) for ls, ds in zip(res["label"], res["dist"]) for l, d in zip(ls, ds)]
+    assert got == want

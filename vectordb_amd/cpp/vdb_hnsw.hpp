@@ -1,0 +1,202 @@
+// vdb_hnsw.hpp — the reference's C++ index interface on top of the C-ABI (include/vdb_index.h).
+//
+// A user of the reference's src/hnsw/hnsw_scratch keeps their code: the class and method names,
+// argument meaning, return types and error behaviour (std::runtime_error) are those of
+//   AlgorithmInterface<dist_t>        hnswlib.hpp:71-99
+//   SpaceInterface / L2Space / InnerProductSpace   hnswlib.hpp:54-61, space_l2.hpp:16-37, space_ip.hpp:20-41
+//   HierarchicalNSW<dist_t>           hnsw_core.hpp:21 (ctor :118-123, load ctor :110-116,
+//                                     setefSearch :207, searchKnn :1107, markDelete :709, ...)
+//   BruteforceSearch<dist_t>          bruteforce.hpp:14
+// with dist_t = float.  Building runs on the host (reference algorithm); every search runs the
+// gfx950 kernels.  The index is uploaded lazily on the first search after a change; a batch
+// entry point (searchKnnBatch) is added because one query per call cannot fill a GPU.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <limits>
+#include <queue>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/vdb_index.h"
+
+namespace vdb_amd {
+
+using labeltype = size_t;
+
+class BaseFilterFunctor {  // hnswlib.hpp:64-68
+public:
+    virtual bool operator()(labeltype) { return true; }
+    virtual ~BaseFilterFunctor() {}
+};
+
+template <typename dist_t>
+class AlgorithmInterface {  // hnswlib.hpp:71-99
+public:
+    virtual void addPoint(const void* datapoint, labeltype label, bool replace_deleted = false) = 0;
+    virtual std::priority_queue<std::pair<dist_t, labeltype>> SearchKNN(const void* query, size_t k,
+                                                                        BaseFilterFunctor* filter = nullptr) const = 0;
+    virtual std::vector<std::pair<dist_t, labeltype>> SearchKNNCloserFirst(const void* query, size_t k,
+                                                                           BaseFilterFunctor* filter = nullptr) const {
+        auto heap = SearchKNN(query, k, filter);
+        std::vector<std::pair<dist_t, labeltype>> out(heap.size());
+        for (size_t i = heap.size(); i > 0; --i) {
+            out[i - 1] = heap.top();
+            heap.pop();
+        }
+        return out;
+    }
+    virtual void saveIndex(const std::string& location) = 0;
+    virtual ~AlgorithmInterface() = default;
+};
+
+struct SpaceInterface {  // hnswlib.hpp:54-61; the distance itself runs on the device
+    size_t dim;
+    int metric;
+    size_t get_data_size() const { return dim * sizeof(float); }
+    size_t get_dim() const { return dim; }
+};
+struct L2Space : SpaceInterface {
+    explicit L2Space(size_t d) : SpaceInterface{d, VDB_L2} {}
+};
+struct InnerProductSpace : SpaceInterface {
+    explicit InnerProductSpace(size_t d) : SpaceInterface{d, VDB_IP} {}
+};
+
+inline void vdb_check(int rc) {
+    if (rc != VDB_OK) throw std::runtime_error(vdb_last_error());
+}
+
+class HierarchicalNSW : public AlgorithmInterface<float> {
+public:
+    HierarchicalNSW(const SpaceInterface* s, size_t capacity, size_t M = 16, size_t efConstruction = 200,
+                    size_t random_seed = 100, bool reuse_deleted = false, int device = 0)
+        : device_(device) {
+        if (reuse_deleted) throw std::runtime_error("reuse_deleted is not implemented");
+        vdb_check(vdb_index_create(&idx_, s->metric, s->dim, capacity, M, efConstruction, random_seed));
+    }
+    HierarchicalNSW(const SpaceInterface* s, const std::string& location, bool /*nmslib*/ = false, size_t capacity = 0,
+                    int device = 0)
+        : device_(device) {
+        vdb_check(vdb_index_load(&idx_, location.c_str(), s->metric, s->dim, capacity));
+    }
+    ~HierarchicalNSW() override { vdb_index_free(idx_); }
+    HierarchicalNSW(const HierarchicalNSW&) = delete;
+    HierarchicalNSW& operator=(const HierarchicalNSW&) = delete;
+
+    void addPoint(const void* datapoint, labeltype label, bool replace_deleted = false) override {
+        if (replace_deleted) throw std::runtime_error("Replacement of deleted elements is disabled in constructor");
+        vdb_check(vdb_index_add(idx_, static_cast<const float*>(datapoint), label, -1));
+        dirty_ = true;
+    }
+    void addPoints(const float* vecs, const uint64_t* labels, size_t n, int n_threads) {
+        vdb_check(vdb_index_add_batch(idx_, vecs, labels, n, n_threads));
+        dirty_ = true;
+    }
+    void saveIndex(const std::string& location) override { vdb_check(vdb_index_save(idx_, location.c_str())); }
+    void setefSearch(size_t ef) { vdb_check(vdb_index_set_ef(idx_, ef)); }
+    size_t getCapacity() const { return vdb_index_capacity(idx_); }
+    size_t getElementCount() const { return vdb_index_count(idx_); }
+    size_t getDeletedCount() const { return vdb_index_deleted_count(idx_); }
+    void markDelete(labeltype label) {
+        vdb_check(vdb_index_mark_delete(idx_, label));
+        dirty_ = true;
+    }
+    void unmarkDelete(labeltype label) {
+        vdb_check(vdb_index_unmark_delete(idx_, label));
+        dirty_ = true;
+    }
+    void resizeIndex(size_t new_capacity) {
+        vdb_check(vdb_index_resize(idx_, new_capacity));
+        dirty_ = true;
+    }
+    void checkIntegrity() const {
+        if (vdb_index_check_integrity(idx_, nullptr, nullptr) != 0) throw std::runtime_error("integrity check failed");
+    }
+
+    // nq queries at once: out_dist/out_label [nq*k], closest first, padded with +inf / SIZE_MAX.
+    void searchKnnBatch(const float* queries, size_t nq, size_t k, float* out_dist, uint64_t* out_label) const {
+        sync_device();
+        vdb_check(vdb_search_batch(idx_, queries, nq, k, out_dist, out_label, nullptr));
+    }
+    // hnsw_core.hpp:1107-1159: max-heap of (dist, label)
+    std::priority_queue<std::pair<float, labeltype>> searchKnn(const void* query, size_t k,
+                                                               BaseFilterFunctor* filter = nullptr) const {
+        if (filter) throw std::runtime_error("filtered search is not on the device path yet");
+        std::vector<float> d(k);
+        std::vector<uint64_t> l(k);
+        searchKnnBatch(static_cast<const float*>(query), 1, k, d.data(), l.data());
+        std::priority_queue<std::pair<float, labeltype>> out;
+        for (size_t i = 0; i < k; ++i)
+            if (l[i] != std::numeric_limits<uint64_t>::max()) out.emplace(d[i], (labeltype)l[i]);
+        return out;
+    }
+    std::priority_queue<std::pair<float, labeltype>> SearchKNN(const void* query, size_t k,
+                                                               BaseFilterFunctor* filter = nullptr) const override {
+        return searchKnn(query, k, filter);
+    }
+    vdb_index* handle() const { return idx_; }
+
+private:
+    void sync_device() const {
+        if (dirty_ || vdb_index_device_bytes(idx_) == 0) {
+            vdb_check(vdb_index_to_device(idx_, device_));
+            dirty_ = false;
+        }
+    }
+    vdb_index* idx_ = nullptr;
+    int device_ = 0;
+    mutable bool dirty_ = true;
+};
+
+class BruteforceSearch : public AlgorithmInterface<float> {
+public:
+    BruteforceSearch(const SpaceInterface* s, size_t maxElements, int device = 0) : device_(device) {
+        vdb_check(vdb_bf_create(&bf_, s->metric, s->dim, maxElements));
+    }
+    BruteforceSearch(const SpaceInterface* s, const std::string& location, int device = 0) : device_(device) {
+        vdb_check(vdb_bf_load(&bf_, location.c_str(), s->metric, s->dim));
+    }
+    ~BruteforceSearch() override { vdb_bf_free(bf_); }
+    BruteforceSearch(const BruteforceSearch&) = delete;
+    BruteforceSearch& operator=(const BruteforceSearch&) = delete;
+
+    void addPoint(const void* datapoint, labeltype label, bool = false) override {
+        uint64_t l = label;
+        vdb_check(vdb_bf_add_batch(bf_, static_cast<const float*>(datapoint), &l, 1));
+        dirty_ = true;
+    }
+    void removePoint(labeltype label) {
+        vdb_check(vdb_bf_remove(bf_, label));
+        dirty_ = true;
+    }
+    void saveIndex(const std::string& location) override { vdb_check(vdb_bf_save(bf_, location.c_str())); }
+    void searchKnnBatch(const float* queries, size_t nq, size_t k, float* out_dist, uint64_t* out_label,
+                        int precision = VDB_BF_FP32) const {
+        if (dirty_) {
+            vdb_check(vdb_bf_to_device(bf_, device_));
+            dirty_ = false;
+        }
+        vdb_check(vdb_bf_search_batch(bf_, queries, nq, k, precision, out_dist, out_label));
+    }
+    std::priority_queue<std::pair<float, labeltype>> SearchKNN(const void* query, size_t k,
+                                                               BaseFilterFunctor* filter = nullptr) const override {
+        if (filter) throw std::runtime_error("filtered search is not on the device path yet");
+        std::vector<float> d(k);
+        std::vector<uint64_t> l(k);
+        searchKnnBatch(static_cast<const float*>(query), 1, k, d.data(), l.data());
+        std::priority_queue<std::pair<float, labeltype>> out;
+        for (size_t i = 0; i < k; ++i)
+            if (l[i] != std::numeric_limits<uint64_t>::max()) out.emplace(d[i], (labeltype)l[i]);
+        return out;
+    }
+
+private:
+    vdb_bruteforce* bf_ = nullptr;
+    int device_ = 0;
+    mutable bool dirty_ = true;
+};
+
+}  // namespace vdb_amd
