@@ -44,9 +44,9 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000, help="base vectors (default = the named workload)")
+    ap.add_argument("--base-rows", dest="n", type=int, default=1_000_000, help="base vectors (default = the named workload)")
     ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--queries", dest="nq", type=int, default=10_000)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--M", type=int, default=16)
     ap.add_argument("--efc", type=int, default=200)
@@ -64,10 +64,17 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # rehearsal on a one-GPU box only: VDB_BENCH_REHEARSAL=1 puts every rank on device 0 over gloo
+    rehearsal = os.environ.get("VDB_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from vectordb_amd import datasets
     from vectordb_amd import index as vi
@@ -197,7 +204,7 @@ def main() -> None:
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on the host cores --
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc  # the checker/baseline, never the product path
         orc.build()
         with tempfile.TemporaryDirectory() as d:
