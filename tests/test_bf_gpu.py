@@ -65,9 +65,11 @@ def test_bruteforce_empty_and_errors():
     with pytest.raises(vi.VdbError):          # stale device copy
         b.search_batch(np.zeros((3, 8), np.float32), 2)
     b.to_device(0)
+    d, l = b.search_batch(np.zeros((3, 8), np.float32), 2, precision=vi.BF_BF16)   # tiny index through the MFMA path
+    assert sorted(l[0].tolist()) == [0, 1] and np.allclose(d, 8.0, rtol=1e-2)
     with pytest.raises(vi.VdbError) as e:
-        b.search_batch(np.zeros((3, 8), np.float32), 2, precision=vi.BF_BF16)
-    assert e.value.code == 4
+        b.search_batch(np.zeros((3, 8), np.float32), 2, precision=7)
+    assert e.value.code == 1
 
 
 def test_hnsw_full_ef_equals_bruteforce_on_device():
@@ -105,3 +107,73 @@ def test_merge_topk_kernel(G, nq, k):
     o = np.lexsort((alll, alld), axis=1)[:, :k]
     np.testing.assert_array_equal(md.cpu().numpy(), np.take_along_axis(alld, o, 1))
     np.testing.assert_array_equal(ml.cpu().numpy().view(np.uint64), np.take_along_axis(alll, o, 1))
+
+
+# ---- MFMA candidate pass (bf_mfma.hip): n >= 8192 routes VDB_BF_FP32 through it ------------
+
+@pytest.mark.parametrize("n,dim,metric,k", [
+    (20000, 128, vi.L2, 10),
+    (12000, 96, vi.IP, 10),
+    (9000, 40, vi.L2, 1),
+    (8500, 960, vi.L2, 100),
+    (10000, 200, vi.IP, 33),
+])
+def test_mfma_fp32_path_is_exact(orc, n, dim, metric, k):
+    x = datasets.clustered(n, dim, 31, normalize=(metric == vi.IP))
+    q = datasets.clustered(150, dim, 32, normalize=(metric == vi.IP))
+    labels = (np.arange(n, dtype=np.uint64) * 3 + 11)
+    space = vi.L2Space(dim) if metric == vi.L2 else vi.InnerProductSpace(dim)
+    b = vi.BruteforceSearch(space, n)
+    b.add_items(x, labels)
+    b.to_device(0)
+    d, l = b.search_batch(q, k, precision=vi.BF_FP32)
+    r = oracle_bf(orc, x, labels, metric, q, k)
+    np.testing.assert_array_equal(l, r["label"].astype(np.uint64))
+    np.testing.assert_array_equal(d.view(np.uint32), r["dist"].view(np.uint32))
+
+
+def test_mfma_fp32_ties_fall_back_to_exact(orc):
+    """Duplicated rows: the k-th exact distance equals distances the candidate pass dropped, the
+    certificate cannot hold, and the exact scan re-runs those queries."""
+    rng = np.random.default_rng(9)
+    base = rng.random((300, 48), dtype=np.float32)
+    x = np.concatenate([base] * 40)[rng.permutation(12000)]
+    labels = (5_000_000_000 - np.arange(12000)).astype(np.uint64)
+    q = np.concatenate([base[:40], rng.random((24, 48), dtype=np.float32)])
+    b = vi.BruteforceSearch(vi.L2Space(48), 12000)
+    b.add_items(x, labels)
+    b.to_device(0)
+    for k in (10, 45, 90):
+        d, l = b.search_batch(q, k)
+        r = oracle_bf(orc, x, labels, vi.L2, q, k)
+        np.testing.assert_array_equal(l, r["label"].astype(np.uint64))
+        np.testing.assert_array_equal(d.view(np.uint32), r["dist"].view(np.uint32))
+
+
+@pytest.mark.parametrize("dim,metric", [(128, vi.L2), (960, vi.L2), (96, vi.IP)])
+def test_mfma_bf16_paths(orc, dim, metric):
+    n, k = 30000, 10
+    x = datasets.clustered(n, dim, 41, normalize=(metric == vi.IP))
+    q = datasets.clustered(200, dim, 42, normalize=(metric == vi.IP))
+    space = vi.L2Space(dim) if metric == vi.L2 else vi.InnerProductSpace(dim)
+    b = vi.BruteforceSearch(space, n)
+    b.add_items(x)
+    b.to_device(0)
+    r = oracle_bf(orc, x, None, metric, q, k)
+    truth = r["label"].astype(np.uint64)
+    # bf16 candidates + exact re-rank: every returned distance is the exact one of its label
+    d2, l2 = b.search_batch(q, k, precision=vi.BF_BF16_RERANK)
+    assert datasets.recall_at_k(l2, truth) >= 0.99
+    allq = orc.OracleBruteforce(metric, dim, n, mode=orc.TREE64)
+    allq.add(x)
+    for i in range(0, 200, 37):
+        for j in range(k):
+            assert d2[i, j] == np.float32(orc.distance(metric, orc.TREE64, q[i], x[int(l2[i, j])]))
+    assert np.all(np.diff(d2, axis=1) >= 0)
+    # bf16 only: distances are bf16-grade, recall reported separately
+    d1, l1 = b.search_batch(q, k, precision=vi.BF_BF16)
+    rec = datasets.recall_at_k(l1, truth)
+    assert rec >= 0.85, rec
+    exact = np.array([[orc.distance(metric, orc.TREE64, q[i], x[int(l1[i, j])]) for j in range(k)] for i in range(0, 200, 20)])
+    scale = np.abs(exact).max()
+    np.testing.assert_allclose(d1[0:200:20], exact, atol=0.02 * scale)

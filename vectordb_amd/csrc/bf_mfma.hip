@@ -1,0 +1,511 @@
+// bf_mfma.hip — MFMA candidate pass of the brute-force k-NN (north star: "brute-force
+// L2/inner-product over query-by-base tiles uses MFMA (bf16/fp32), computed as
+// ||x||^2 - 2 q.x + ||q||^2"), in front of the exact re-rank.
+//
+// Reference semantics stay those of bruteforce.hpp:147-184 (the k smallest (dist, label)); the
+// reference has no counterpart for the arithmetic below, which only PROPOSES candidates:
+//
+//   prepare (vdb_bf_to_device)   mean vector mu, centred copies xc = x - mu in f32 and bf16,
+//                                ||xc||^2 per row.  Centring leaves L2 distances unchanged and
+//                                shifts inner products by a per-query constant, and makes the
+//                                f32/bf16 products an order of magnitude more accurate.
+//   bf_prep_queries              qc = q - mu (L2) / q (IP), per-query offset and error bound.
+//   bf_gemm_filter<BF16>         128 base rows x 128 queries per block, 4 waves of 64x64,
+//                                v_mfma_f32_32x32x2_f32 or v_mfma_f32_32x32x16_bf16; the epilogue
+//                                turns dots into approximate distances and appends the pairs
+//                                that beat the query's running threshold to its candidate buffer.
+//   bf_compact (bf_search.hip)   keeps the k' best approximate candidates, publishes the
+//                                threshold for the next slab of base rows.
+//   bf_rerank                    exact tree64 distances of the k' survivors (the oracle's
+//                                arithmetic), and the certificate: everything the candidate pass
+//                                dropped is farther than tau_hat - eps.
+//   bf_compact (final)           exact top-k by (dist, label); a query whose k-th exact distance
+//                                is not below its certificate is re-run by the exact scan, so
+//                                VDB_BF_FP32 results equal the CPU path bit for bit.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "bf_internal.hpp"
+#include "device_index.hpp"
+#include "launch.hpp"
+
+namespace vdb {
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t u) {
+    return __builtin_bit_cast(float, (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------ index preparation
+
+constexpr int kSumBlocks = 256;
+
+// partial[b][c] = sum over the rows of block b of x[row][c]   (f64, fixed order: deterministic)
+__global__ __launch_bounds__(256) void bf_colsum_partial(const float* x, uint32_t n, uint32_t vstride, double* partial) {
+    const uint32_t per = (n + kSumBlocks - 1) / kSumBlocks;
+    const uint32_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (uint32_t c = threadIdx.x; c < vstride; c += 256) {
+        double s = 0.0;
+        for (uint32_t r = lo; r < hi; ++r) s += (double)x[(size_t)r * vstride + c];
+        partial[(size_t)blockIdx.x * vstride + c] = s;
+    }
+}
+
+// mu[c] = sum / n ; stats[0] = 0 (max ||xc||, filled by bf_center), stats[1] = ||mu||
+__global__ __launch_bounds__(256) void bf_colsum_final(const double* partial, uint32_t n, uint32_t vstride, float* mu,
+                                                       float* stats) {
+    __shared__ double s_sq[256];
+    double sq = 0.0;
+    for (uint32_t c = threadIdx.x; c < vstride; c += 256) {
+        double s = 0.0;
+        for (int b = 0; b < kSumBlocks; ++b) s += partial[(size_t)b * vstride + c];
+        const float m = n ? (float)(s / (double)n) : 0.f;
+        mu[c] = m;
+        sq += (double)m * (double)m;
+    }
+    s_sq[threadIdx.x] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 256; ++i) t += s_sq[i];
+        stats[0] = 0.f;
+        stats[1] = (float)__builtin_sqrt(t);
+    }
+}
+
+// one wave per row: xc = x - mu (f32), bf16(xc), ||xc||^2, running max of ||xc||
+__global__ __launch_bounds__(256) void bf_center(const float* x, uint32_t n, uint32_t dim, uint32_t vstride, uint32_t kp64,
+                                                 const float* mu, float* xc, __bf16* xb, float* nx, float* stats) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    double s = 0.0;
+    for (uint32_t c = lane; c < kp64; c += 64) {
+        float v = 0.f;
+        if (c < dim) v = x[(size_t)row * vstride + c] - mu[c];
+        if (c < vstride) xc[(size_t)row * vstride + c] = v;
+        xb[(size_t)row * kp64 + c] = (__bf16)v;
+        s += (double)v * (double)v;
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        nx[row] = (float)s;
+        const float norm = (float)__builtin_sqrt(s) * 1.0000002f;  // round up: it feeds an error BOUND
+        atomicMax(reinterpret_cast<uint32_t*>(stats), __builtin_bit_cast(uint32_t, norm));
+    }
+}
+
+// ------------------------------------------------------------------ query preparation
+
+struct QPrepArgs {
+    const float* queries;  // [nq][dim]
+    uint32_t nq, dim, vstride, kp64;
+    int32_t metric;
+    const float* mu;
+    const float* stats;  // [0] max ||xc||, [1] ||mu||
+    float* qf;           // [nq][vstride]
+    __bf16* qb;          // [nq][kp64]
+    float* off;          // [nq]  dist ~= score + off
+    float* eps;          // [nq]  |approx dist - exact tree64 dist| <= eps  (f32 pass)
+};
+
+__global__ __launch_bounds__(256) void bf_prep_queries(QPrepArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= a.nq) return;
+    const bool is_l2 = a.metric == 0;
+    double sq = 0.0, qmu = 0.0;
+    for (uint32_t c = lane; c < a.kp64; c += 64) {
+        float v = 0.f;
+        if (c < a.dim) {
+            const float raw = a.queries[(size_t)q * a.dim + c];
+            v = is_l2 ? raw - a.mu[c] : raw;
+            qmu += (double)raw * (double)a.mu[c];
+        }
+        if (c < a.vstride) a.qf[(size_t)q * a.vstride + c] = v;
+        a.qb[(size_t)q * a.kp64 + c] = (__bf16)v;
+        sq += (double)v * (double)v;
+    }
+    sq = wave_sum(sq);
+    qmu = wave_sum(qmu);
+    if (lane == 0) {
+        const double qn = __builtin_sqrt(sq), xmax = a.stats[0], mun = a.stats[1];
+        const double u = 5.9604644775390625e-08;  // 2^-24
+        const double K = (double)a.vstride;
+        if (is_l2) {
+            a.off[q] = (float)sq;
+            a.eps[q] = (float)(2.0 * (K + 16.0) * u * (qn + xmax) * (qn + xmax) * 1.0001);
+        } else {
+            a.off[q] = (float)(1.0 - qmu);
+            a.eps[q] = (float)(2.0 * (K + 16.0) * u * (qn * (xmax + mun) + 1.0) * 1.0001);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ GEMM + filter
+
+struct GemmArgs {
+    const void* A;  // centred base rows, f32 [n][ld] or bf16 [n][ld]
+    const void* B;  // prepared queries, same element type and row length
+    uint32_t ld;    // elements per row
+    uint32_t ksteps;
+    const float* nx;
+    const float* off;
+    int32_t metric;
+    uint32_t row_lo, row_hi, nq, cap;
+    uint32_t* count;
+    const uint32_t* tauhat;  // [nq] ordered-u32 threshold on the approximate distance
+    uint64_t* entries;       // [nq][cap]  ord(approx dist) << 32 | row
+};
+
+constexpr int kLdw = 36;  // LDS row stride in 4-byte words: 128 B of data + 16 B pad (conflict-free b128)
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void bf_gemm_filter(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t As[128 * kLdw];
+    __shared__ __attribute__((aligned(16))) uint32_t Bs[128 * kLdw];
+    __shared__ float nx_s[128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, h = lane >> 5, li = lane & 31;
+    const uint32_t row0 = a.row_lo + blockIdx.x * 128u, q0 = blockIdx.y * 128u;
+    const size_t row_bytes = (size_t)a.ld * (BF16 ? 2 : 4);
+    const char* Ab = static_cast<const char*>(a.A);
+    const char* Bb = static_cast<const char*>(a.B);
+
+    if (tid < 128) nx_s[tid] = row0 + tid < a.row_hi ? a.nx[row0 + tid] : 0.f;
+
+    uint4 ra[4], rb[4];
+    auto gload = [&](uint32_t ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * 256, r = idx >> 3, c = idx & 7;
+            const uint32_t row = row0 + r, q = q0 + r;
+            ra[i] = make_uint4(0u, 0u, 0u, 0u);
+            rb[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (row < a.row_hi) ra[i] = *reinterpret_cast<const uint4*>(Ab + (size_t)row * row_bytes + (size_t)ks * 128 + c * 16);
+            if (q < a.nq) rb[i] = *reinterpret_cast<const uint4*>(Bb + (size_t)q * row_bytes + (size_t)ks * 128 + c * 16);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * 256, r = idx >> 3, c = idx & 7;
+            *reinterpret_cast<uint4*>(&As[r * kLdw + c * 4]) = ra[i];
+            *reinterpret_cast<uint4*>(&Bs[r * kLdw + c * 4]) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    gload(0);
+    for (uint32_t ks = 0; ks < a.ksteps; ++ks) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (ks + 1 < a.ksteps) gload(ks + 1);
+        const uint32_t* arow[2] = {&As[(wr * 64 + li) * kLdw], &As[(wr * 64 + 32 + li) * kLdw]};
+        const uint32_t* brow[2] = {&Bs[(wc * 64 + li) * kLdw], &Bs[(wc * 64 + 32 + li) * kLdw]};
+        if constexpr (BF16) {
+            // 64 bf16 per row per step = 4 MFMA k-blocks of 16; lane half h owns k = 16 s + 8 h .. +7
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 af[2], bfr[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) af[m] = *reinterpret_cast<const bf16x8*>(arow[m] + s * 8 + h * 4);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) bfr[n] = *reinterpret_cast<const bf16x8*>(brow[n] + s * 8 + h * 4);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+            }
+        } else {
+            // 32 f32 per row per step; lane half h owns k = 16 h .. 16 h + 15 (A and B alike)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 af[2], bfr[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) af[m] = *reinterpret_cast<const f32x4*>(arow[m] + h * 16 + j * 4);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) bfr[n] = *reinterpret_cast<const f32x4*>(brow[n] + h * 16 + j * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][c], bfr[n][c], acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: column = query (lane & 31), registers = base rows
+    const bool is_l2 = a.metric == 0;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const uint32_t q = q0 + wc * 64 + n * 32 + li;
+        const bool qok = q < a.nq;
+        const uint32_t tauh = qok ? a.tauhat[q] : 0u;
+        const float offq = qok ? a.off[q] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rin = wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const uint32_t row = row0 + rin;
+                const float dot = acc[m][n][r];
+                const float s = is_l2 ? nx_s[rin] - 2.0f * dot : -dot;
+                const uint32_t od = f2ord(s + offq);
+                if (qok && row < a.row_hi && od <= tauh) {
+                    const uint32_t pos = atomicAdd(&a.count[q], 1u);
+                    if (pos < a.cap) a.entries[(size_t)q * a.cap + pos] = ((uint64_t)od << 32) | row;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ exact re-rank
+
+struct RerankArgs {
+    const float* raw;      // [n][vstride] original rows
+    const float* queries;  // [nq][dim] original queries
+    uint32_t nq, dim, vstride, cap;
+    int32_t metric;
+    const uint32_t* count;
+    const uint32_t* tauhat;
+    const float* eps;
+    uint64_t* entries;  // in: approximate keys, out: exact keys
+    float* cert;        // [nq]
+};
+
+// one wave per query; the distance code is the tree64 engine of hnsw_search.hip / bf_scan_exact
+__global__ __launch_bounds__(64) void bf_rerank(RerankArgs a) {
+    const int lane = threadIdx.x, grp = lane >> 4, t = lane & 15;
+    const uint32_t q = blockIdx.x;
+    uint32_t cnt = a.count[q];
+    if (cnt > a.cap) cnt = a.cap;
+    uint64_t* ent = a.entries + (size_t)q * a.cap;
+    const bool is_l2 = a.metric == 0;
+    const float* qp = a.queries + (size_t)q * a.dim;
+    const uint32_t nch = (a.vstride + 63u) / 64u;
+    for (uint32_t base = 0; base < cnt; base += 4) {
+        const uint32_t i = base + grp;
+        const bool live = i < cnt;
+        const uint32_t row = live ? (uint32_t)ent[i] : 0u;
+        const float* xr = a.raw + (size_t)row * a.vstride;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (uint32_t j = 0; j < nch; ++j) {
+            const uint32_t e = 64 * j + 4 * t;
+            f32x4 x = f32x4{0.f, 0.f, 0.f, 0.f};
+            float qv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (live && e < a.vstride) x = *reinterpret_cast<const f32x4*>(xr + e);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (e + c < a.dim) qv[c] = qp[e + c];
+            if (is_l2) {
+                const float d0 = qv[0] - x.x, d1 = qv[1] - x.y, d2 = qv[2] - x.z, d3 = qv[3] - x.w;
+                a0 = __builtin_fmaf(d0, d0, a0);
+                a1 = __builtin_fmaf(d1, d1, a1);
+                a2 = __builtin_fmaf(d2, d2, a2);
+                a3 = __builtin_fmaf(d3, d3, a3);
+            } else {
+                a0 = __builtin_fmaf(qv[0], x.x, a0);
+                a1 = __builtin_fmaf(qv[1], x.y, a1);
+                a2 = __builtin_fmaf(qv[2], x.z, a2);
+                a3 = __builtin_fmaf(qv[3], x.w, a3);
+            }
+        }
+        float s = (a0 + a1) + (a2 + a3);
+        s = s + dpp_f32<kDppXor1>(s);
+        s = s + dpp_f32<kDppXor2>(s);
+        s = s + dpp_f32<kDppHalfMirror>(s);
+        s = s + dpp_f32<kDppMirror>(s);
+        if (!is_l2) s = 1.0f - s;
+        if (live && t == 0) ent[i] = ((uint64_t)f2ord(s) << 32) | row;
+    }
+    if (lane == 0 && a.cert) {
+        const uint32_t th = a.tauhat[q];
+        a.cert[q] = th == 0xFFFFFFFFu ? __builtin_inff() : ord2f(th) - a.eps[q];
+    }
+}
+
+template <typename T>
+T* carve(char*& p, size_t count) {
+    T* r = reinterpret_cast<T*>(p);
+    p += (count * sizeof(T) + 255) / 256 * 256;
+    return r;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------- host side
+
+size_t bf_prepare_scratch_bytes(uint32_t vstride) { return (size_t)kSumBlocks * vstride * 8; }
+
+int launch_bf_prepare(const float* d_raw, uint32_t n, uint32_t dim, uint32_t vstride, uint32_t kp64, float* d_xc,
+                      void* d_xb, float* d_nx, float* d_mu, float* d_stats, void* d_scratch, hipStream_t stream,
+                      std::string* err) {
+    double* partial = static_cast<double*>(d_scratch);
+    hipLaunchKernelGGL(bf_colsum_partial, dim3(kSumBlocks), dim3(256), 0, stream, d_raw, n, vstride, partial);
+    hipLaunchKernelGGL(bf_colsum_final, dim3(1), dim3(256), 0, stream, partial, n, vstride, d_mu, d_stats);
+    if (n)
+        hipLaunchKernelGGL(bf_center, dim3((n + 3) / 4), dim3(256), 0, stream, d_raw, n, dim, vstride, kp64, d_mu, d_xc,
+                           static_cast<__bf16*>(d_xb), d_nx, d_stats);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (err) *err = std::string("brute-force prepare failed: ") + hipGetErrorString(e);
+        return 3;
+    }
+    return 0;
+}
+
+uint32_t bf_mfma_kprime(uint32_t k, int precision) {
+    uint32_t kp = precision == 0 ? k + 32 : (4 * k > k + 96 ? 4 * k : k + 96);
+    if (kp > kBfMfmaCap / 2) kp = kBfMfmaCap / 2;
+    return kp < k ? k : kp;
+}
+
+size_t bf_mfma_workspace_bytes(uint32_t nq, uint32_t vstride, uint32_t kp64) {
+    size_t b = 0;
+    auto add = [&](size_t bytes) { b += (bytes + 255) / 256 * 256; };
+    add((size_t)nq * 4);                  // count
+    add((size_t)nq * 4);                  // tauhat
+    add((size_t)nq * 4);                  // overflow
+    add((size_t)nq * kBfMfmaCap * 8);     // entries
+    add((size_t)nq * vstride * 4);        // qf
+    add((size_t)nq * kp64 * 2);           // qb
+    add((size_t)nq * 4 * 3);              // off, eps, cert
+    add(((size_t)nq + 1) * 4);            // redo
+    return b + 4096 + bf_exact_workspace_bytes(nq);
+}
+
+int launch_bf_mfma(const BfDeviceData& d, int precision, const float* d_queries, uint32_t nq, uint32_t k, float* d_out_dist,
+                   uint64_t* d_out_label, void* workspace, hipStream_t stream, std::string* err) {
+    if (nq == 0) return 0;
+    const bool bf16 = precision != 0;
+    const bool rerank = precision != 1;
+    const bool certify = precision == 0;
+    const uint32_t kprime = bf_mfma_kprime(k, precision);
+
+    char* p = static_cast<char*>(workspace);
+    uint32_t* count = carve<uint32_t>(p, nq);
+    uint32_t* tauhat = carve<uint32_t>(p, nq);
+    uint32_t* overflow = carve<uint32_t>(p, nq);
+    uint64_t* entries = carve<uint64_t>(p, (size_t)nq * kBfMfmaCap);
+    float* qf = carve<float>(p, (size_t)nq * d.vstride);
+    __bf16* qb = carve<__bf16>(p, (size_t)nq * d.kp64);
+    float* off = carve<float>(p, nq);
+    float* eps = carve<float>(p, nq);
+    float* cert = carve<float>(p, nq);
+    uint32_t* redo = carve<uint32_t>(p, (size_t)nq + 1);
+    void* exact_ws = p;
+
+    hipError_t e = hipMemsetAsync(count, 0, (size_t)nq * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(tauhat, 0xFF, (size_t)nq * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(overflow, 0, (size_t)nq * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(redo, 0, 4, stream);
+    if (e != hipSuccess) {
+        if (err) *err = std::string("hipMemsetAsync: ") + hipGetErrorString(e);
+        return 3;
+    }
+
+    QPrepArgs qa{d_queries, nq, d.dim, d.vstride, d.kp64, d.metric, d.mu, d.stats, qf, qb, off, eps};
+    hipLaunchKernelGGL(bf_prep_queries, dim3((nq + 3) / 4), dim3(256), 0, stream, qa);
+
+    GemmArgs g{};
+    g.A = bf16 ? static_cast<const void*>(d.xb) : static_cast<const void*>(d.xc);
+    g.B = bf16 ? static_cast<const void*>(qb) : static_cast<const void*>(qf);
+    g.ld = bf16 ? d.kp64 : d.vstride;
+    g.ksteps = bf16 ? d.kp64 / 64 : d.vstride / 32;
+    g.nx = d.nx;
+    g.off = off;
+    g.metric = d.metric;
+    g.nq = nq;
+    g.cap = kBfMfmaCap;
+    g.count = count;
+    g.tauhat = tauhat;
+    g.entries = entries;
+
+    CompactArgs c{};
+    c.nq = nq;
+    c.k = kprime;
+    c.cap = kBfMfmaCap;
+    c.count = count;
+    c.tau = tauhat;
+    c.entries = entries;
+    c.labels = d.labels;
+    c.overflow = overflow;
+    c.final_pass = 0;
+
+    // slabs: the first can fill a buffer completely, later ones grow with the rows already seen
+    // (a slab of S rows behind m seen rows appends ~ k' S / m candidates per query)
+    uint32_t lo = 0;
+    while (lo < d.n) {
+        uint32_t slab = lo == 0 ? kBfMfmaCap - kprime : (lo < kBfMaxSlab ? lo : kBfMaxSlab);
+        slab = slab / 128 * 128;
+        const uint32_t hi = d.n - lo > slab ? lo + slab : d.n;
+        g.row_lo = lo;
+        g.row_hi = hi;
+        const dim3 grid((hi - lo + 127) / 128, (nq + 127) / 128);
+        if (bf16) hipLaunchKernelGGL((bf_gemm_filter<true>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((bf_gemm_filter<false>), grid, dim3(256), 0, stream, g);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = enqueue_bf_compact(c, stream);
+        if (e != hipSuccess) break;
+        lo = hi;
+    }
+    if (e == hipSuccess && rerank) {
+        RerankArgs r{d.raw, d_queries, nq, d.dim, d.vstride, kBfMfmaCap, d.metric, count, tauhat, eps, entries,
+                     certify ? cert : nullptr};
+        hipLaunchKernelGGL(bf_rerank, dim3(nq), dim3(64), 0, stream, r);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        c.k = k;
+        c.final_pass = 1;
+        c.out_dist = d_out_dist;
+        c.out_label = d_out_label;
+        c.cert = certify ? cert : nullptr;
+        c.redo = redo;
+        e = enqueue_bf_compact(c, stream);
+    }
+    if (e != hipSuccess) {
+        if (err) *err = std::string("brute-force MFMA launch failed: ") + hipGetErrorString(e);
+        return 3;
+    }
+    if (certify)  // queries the candidate pass could not prove exact: the exact scan, slots taken from `redo`
+        return launch_bf_exact(d.raw, d.labels, d.n, d.dim, d.vstride, d.metric, d_queries, nq, k, d_out_dist, d_out_label,
+                               exact_ws, stream, err, redo + 1, redo);
+    return 0;
+}
+
+}  // namespace vdb

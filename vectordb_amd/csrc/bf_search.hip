@@ -23,6 +23,7 @@
 #include <cstdint>
 #include <string>
 
+#include "bf_internal.hpp"
 #include "device_index.hpp"
 #include "launch.hpp"
 
@@ -62,6 +63,8 @@ struct ScanArgs {
     uint32_t* count;                // [nq]
     const uint32_t* tau;            // [nq] ordered-u32 threshold
     uint64_t* entries;              // [nq][cap]  ord(dist) << 32 | row
+    const uint32_t* qmap;           // nullable: slot i scans query qmap[i] (re-run of flagged queries)
+    const uint32_t* nq_dev;         // nullable: number of live slots, read on the device
 };
 
 constexpr int kScanRowsPerBlock = 256;  // 4 waves x 16 steps x 4 rows
@@ -72,12 +75,15 @@ __global__ __launch_bounds__(256) void bf_scan_exact(ScanArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = lane >> 4, t = lane & 15;
     const uint32_t q0 = blockIdx.y * a.qt;
-    const uint32_t nqt = a.nq - q0 < a.qt ? a.nq - q0 : a.qt;
+    const uint32_t nq_live = a.nq_dev ? *a.nq_dev : a.nq;
+    if (q0 >= nq_live) return;  // block-uniform
+    const uint32_t nqt = nq_live - q0 < a.qt ? nq_live - q0 : a.qt;
     uint32_t* s_tau = reinterpret_cast<uint32_t*>(s_q + (size_t)a.qt * a.vstride);
 
     for (uint32_t i = tid; i < nqt * a.vstride; i += 256) {
         const uint32_t qi = i / a.vstride, e = i - qi * a.vstride;
-        s_q[i] = e < a.dim ? a.queries[(size_t)(q0 + qi) * a.dim + e] : 0.f;
+        const uint32_t src = a.qmap ? a.qmap[q0 + qi] : q0 + qi;
+        s_q[i] = e < a.dim ? a.queries[(size_t)src * a.dim + e] : 0.f;
     }
     for (uint32_t i = tid; i < nqt; i += 256) s_tau[i] = a.tau[q0 + i];
     __syncthreads();
@@ -134,17 +140,6 @@ __global__ __launch_bounds__(256) void bf_scan_exact(ScanArgs a) {
 
 // ------------------------------------------------------------------ compaction / output
 
-struct CompactArgs {
-    uint32_t nq, k, cap;
-    uint32_t* count;
-    uint32_t* tau;
-    uint64_t* entries;
-    const uint64_t* labels;  // [n] label of a row
-    int32_t final_pass;
-    float* out_dist;         // [nq][k]   (final pass)
-    uint64_t* out_label;     // [nq][k]
-};
-
 // ascending bitonic sort of p (power of two, >= 64) keys in LDS by one wave
 __device__ __forceinline__ void bitonic_sort_lds(uint64_t* s, uint32_t p, int lane) {
     for (uint32_t size = 2; size <= p; size <<= 1) {
@@ -168,9 +163,13 @@ __global__ __launch_bounds__(64) void bf_compact(CompactArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t s_key[];  // [cap]
     const int lane = threadIdx.x;
     const uint32_t q = blockIdx.x;
+    if (q >= (a.nq_dev ? *a.nq_dev : a.nq)) return;
     const uint32_t k = a.k;
     uint32_t cnt = a.count[q];
-    if (cnt > a.cap) cnt = a.cap;  // cannot happen: slabs are sized so that buffers never overflow
+    if (cnt > a.cap) {  // exact scan: cannot happen (slab + k <= cap); candidate pass: remembered
+        cnt = a.cap;
+        if (a.overflow && lane == 0) a.overflow[q] = 1u;
+    }
     uint64_t* ent = a.entries + (size_t)q * a.cap;
 
     uint32_t p = 64;
@@ -214,8 +213,18 @@ __global__ __launch_bounds__(64) void bf_compact(CompactArgs a) {
         return;
     }
     // final: ascending (dist, label)
-    float* od = a.out_dist + (size_t)q * k;
-    uint64_t* ol = a.out_label + (size_t)q * k;
+    const uint32_t orow = a.qmap ? a.qmap[q] : q;
+    if (a.cert) {
+        // a candidate pass fed this buffer: everything it dropped is at distance >= cert[q]
+        bool proven = keep < k ? a.cert[q] == __builtin_inff() : ord2f((uint32_t)(s_key[k - 1] >> 32)) < a.cert[q];
+        if (a.overflow && __builtin_amdgcn_readfirstlane((int)a.overflow[q]) != 0) proven = false;
+        if (!proven) {
+            if (lane == 0) a.redo[1 + atomicAdd(&a.redo[0], 1u)] = orow;
+            return;
+        }
+    }
+    float* od = a.out_dist + (size_t)orow * k;
+    uint64_t* ol = a.out_label + (size_t)orow * k;
     for (uint32_t i = lane; i < keep; i += 64) {
         const uint32_t di = (uint32_t)(s_key[i] >> 32);
         const uint64_t li = a.labels[(uint32_t)s_key[i]];
@@ -284,11 +293,17 @@ void launch_scan(const ScanArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
 
 }  // namespace
 
+hipError_t enqueue_bf_compact(const CompactArgs& c, hipStream_t stream) {
+    hipLaunchKernelGGL(bf_compact, dim3(c.nq), dim3(64), (size_t)c.cap * 8, stream, c);
+    return hipGetLastError();
+}
+
 size_t bf_exact_workspace_bytes(uint32_t nq) { return (size_t)nq * (8 + (size_t)kBfCap * 8); }
 
 int launch_bf_exact(const float* d_base, const uint64_t* d_labels, uint32_t n, uint32_t dim, uint32_t vstride,
                     int metric, const float* d_queries, uint32_t nq, uint32_t k, float* d_out_dist,
-                    uint64_t* d_out_label, void* workspace, hipStream_t stream, std::string* err) {
+                    uint64_t* d_out_label, void* workspace, hipStream_t stream, std::string* err,
+                    const uint32_t* d_qmap, const uint32_t* d_nq_live) {
     if (nq == 0) return 0;
     if (k == 0 || k > kBfMaxK) {
         if (err) *err = "brute force: k must be in 1..1024";
@@ -319,6 +334,8 @@ int launch_bf_exact(const float* d_base, const uint64_t* d_labels, uint32_t n, u
     s.count = count;
     s.tau = tau;
     s.entries = entries;
+    s.qmap = d_qmap;
+    s.nq_dev = d_nq_live;
     const size_t scan_lds = (size_t)qt * vstride * 4 + (size_t)qt * 4;
 
     CompactArgs c{};
@@ -331,6 +348,8 @@ int launch_bf_exact(const float* d_base, const uint64_t* d_labels, uint32_t n, u
     c.labels = d_labels;
     c.out_dist = d_out_dist;
     c.out_label = d_out_label;
+    c.qmap = d_qmap;
+    c.nq_dev = d_nq_live;
 
     const uint32_t slab = kBfCap - k;
     const uint32_t nch = (vstride + 63u) / 64u;
@@ -351,8 +370,7 @@ int launch_bf_exact(const float* d_base, const uint64_t* d_labels, uint32_t n, u
         lo = hi;
         c.final_pass = lo >= n ? 1 : 0;
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(bf_compact, dim3(nq), dim3(64), (size_t)kBfCap * 8, stream, c);
-            e = hipGetLastError();
+            e = enqueue_bf_compact(c, stream);
         }
     } while (lo < n && e == hipSuccess);
     if (e != hipSuccess) {

@@ -139,8 +139,8 @@ struct vdb_bruteforce {
     std::unique_ptr<HostBruteforce> host;
     int device = -1;
     uint64_t device_version = ~0ull;
-    DevBuf vecs, labels;
-    uint32_t n = 0, vstride = 0;
+    DevBuf vecs, labels, xc, xb, nx, mu, stats;
+    uint32_t n = 0, vstride = 0, kp64 = 0;
     std::mutex scratch_lock;
     std::map<hipStream_t, std::unique_ptr<DevBuf>> scratch;
 
@@ -152,6 +152,11 @@ struct vdb_bruteforce {
             scratch.clear();
             vecs.release();
             labels.release();
+            xc.release();
+            xb.release();
+            nx.release();
+            mu.release();
+            stats.release();
         } catch (...) {
         }
         device = -1;
@@ -188,8 +193,26 @@ void upload_bf(vdb_bruteforce* bf, int device) {
         VDB_HIP(hipMemcpy((char*)bf->vecs.p + lo * vstride * 4, sv.data(), m * vstride * 4, hipMemcpyHostToDevice));
         VDB_HIP(hipMemcpy((char*)bf->labels.p + lo * 8, sl.data(), m * 8, hipMemcpyHostToDevice));
     }
+    // centred f32 / bf16 copies, norms and the mean for the MFMA candidate pass (bf_mfma.hip)
+    const uint32_t kp64 = (uint32_t)round_up(h.dim, 64);
+    bf->xc.alloc(n * (size_t)vstride * 4);
+    bf->xb.alloc(n * (size_t)kp64 * 2);
+    bf->nx.alloc(n * 4);
+    bf->mu.alloc((size_t)kp64 * 4);
+    bf->stats.alloc(16);
+    {
+        DevBuf tmp;
+        tmp.alloc(bf_prepare_scratch_bytes(vstride));
+        VDB_HIP(hipMemset(bf->mu.p, 0, (size_t)kp64 * 4));
+        std::string err;
+        if (launch_bf_prepare((const float*)bf->vecs.p, (uint32_t)n, (uint32_t)h.dim, vstride, kp64, (float*)bf->xc.p,
+                              bf->xb.p, (float*)bf->nx.p, (float*)bf->mu.p, (float*)bf->stats.p, tmp.p, nullptr, &err) != 0)
+            throw DeviceError(err);
+        VDB_HIP(hipStreamSynchronize(nullptr));
+    }
     bf->n = (uint32_t)n;
     bf->vstride = vstride;
+    bf->kp64 = kp64;
     bf->device = device;
     bf->device_version = h.version;
 }
@@ -613,22 +636,45 @@ int vdb_bf_search_batch_device(const vdb_bruteforce* cbf, const float* d_queries
         if (!d_queries || !d_out_dist || !d_out_label) throw std::invalid_argument("null buffer");
         if (k == 0) throw std::invalid_argument("k must be > 0");
         if (nq > 0x7FFFFFFFull) throw std::invalid_argument("batch too large");
-        if (precision != VDB_BF_FP32) throw Unsupported("bf16 brute-force precisions are not implemented yet");
+        if (precision != VDB_BF_FP32 && precision != VDB_BF_BF16 && precision != VDB_BF_BF16_RERANK)
+            throw std::invalid_argument("unknown brute-force precision");
         if (k > kBfMaxK) throw Unsupported("brute force: k above 1024 is not supported by the device path");
+        // small problems and very large k go straight to the exact scan (same results, no setup cost)
+        const bool exact_only = precision == VDB_BF_FP32 && (bf->n < 4 * kBfMfmaCap || k + 32 > kBfMfmaCap / 2);
         hipStream_t stream = (hipStream_t)stream_;
         DeviceGuard guard(bf->device);
         std::unique_lock<std::mutex> lock(bf->scratch_lock);
         auto& ws = bf->scratch[stream];
         if (!ws) ws.reset(new DevBuf);
-        const size_t need = bf_exact_workspace_bytes((uint32_t)nq);
+        const size_t need = exact_only ? bf_exact_workspace_bytes((uint32_t)nq)
+                                       : bf_mfma_workspace_bytes((uint32_t)nq, bf->vstride, bf->kp64);
         if (ws->bytes < need) {
             if (ws->p) VDB_HIP(hipStreamSynchronize(stream));
             ws->alloc(need);
         }
         std::string err;
-        const int rc = launch_bf_exact((const float*)bf->vecs.p, (const uint64_t*)bf->labels.p, bf->n,
-                                       (uint32_t)bf->host->dim, bf->vstride, bf->host->metric, d_queries, (uint32_t)nq,
-                                       (uint32_t)k, d_out_dist, d_out_label, ws->p, stream, &err);
+        int rc;
+        if (exact_only) {
+            rc = launch_bf_exact((const float*)bf->vecs.p, (const uint64_t*)bf->labels.p, bf->n, (uint32_t)bf->host->dim,
+                                 bf->vstride, bf->host->metric, d_queries, (uint32_t)nq, (uint32_t)k, d_out_dist,
+                                 d_out_label, ws->p, stream, &err);
+        } else {
+            BfDeviceData d;
+            d.raw = (const float*)bf->vecs.p;
+            d.xc = (const float*)bf->xc.p;
+            d.xb = bf->xb.p;
+            d.nx = (const float*)bf->nx.p;
+            d.mu = (const float*)bf->mu.p;
+            d.stats = (const float*)bf->stats.p;
+            d.labels = (const uint64_t*)bf->labels.p;
+            d.n = bf->n;
+            d.dim = (uint32_t)bf->host->dim;
+            d.vstride = bf->vstride;
+            d.kp64 = bf->kp64;
+            d.metric = bf->host->metric;
+            rc = launch_bf_mfma(d, precision, d_queries, (uint32_t)nq, (uint32_t)k, d_out_dist, d_out_label, ws->p,
+                                stream, &err);
+        }
         if (rc != 0) return set_error(rc, err);
         return (int)VDB_OK;
     });

@@ -39,7 +39,34 @@ size_t bf_exact_workspace_bytes(uint32_t nq);
 // slab sweep on `stream`.  Outputs ascending (dist, label), padded with (+inf, UINT64_MAX).
 int launch_bf_exact(const float* d_base, const uint64_t* d_labels, uint32_t n, uint32_t dim, uint32_t vstride,
                     int metric, const float* d_queries, uint32_t nq, uint32_t k, float* d_out_dist,
-                    uint64_t* d_out_label, void* workspace, hipStream_t stream, std::string* err);
+                    uint64_t* d_out_label, void* workspace, hipStream_t stream, std::string* err,
+                    const uint32_t* d_qmap = nullptr, const uint32_t* d_nq_live = nullptr);
+
+// ---- MFMA candidate pass (bf_mfma.hip) ----------------------------------------------------
+constexpr uint32_t kBfMfmaCap = 2048;     // candidate entries per query in the MFMA path
+constexpr uint32_t kBfMaxSlab = 131072;   // base rows per GEMM launch at most
+
+struct BfDeviceData {  // device pointers of an uploaded brute-force index
+    const float* raw = nullptr;     // [n][vstride] original rows, zero-padded
+    const float* xc = nullptr;      // [n][vstride] centred rows x - mu
+    const void* xb = nullptr;       // [n][kp64]    centred rows in bf16
+    const float* nx = nullptr;      // [n]          ||x - mu||^2
+    const float* mu = nullptr;      // [kp64]       mean vector
+    const float* stats = nullptr;   // [0] max ||x - mu||, [1] ||mu||
+    const uint64_t* labels = nullptr;
+    uint32_t n = 0, dim = 0, vstride = 0, kp64 = 0;
+    int metric = 0;
+};
+
+size_t bf_prepare_scratch_bytes(uint32_t vstride);
+int launch_bf_prepare(const float* d_raw, uint32_t n, uint32_t dim, uint32_t vstride, uint32_t kp64, float* d_xc,
+                      void* d_xb, float* d_nx, float* d_mu, float* d_stats, void* d_scratch, hipStream_t stream,
+                      std::string* err);
+size_t bf_mfma_workspace_bytes(uint32_t nq, uint32_t vstride, uint32_t kp64);
+// precision: 0 = f32 MFMA + exact re-rank + certificate (+ exact re-run of unproven queries),
+//            1 = bf16 MFMA only, 2 = bf16 MFMA + exact re-rank (no certificate).
+int launch_bf_mfma(const BfDeviceData& d, int precision, const float* d_queries, uint32_t nq, uint32_t k, float* d_out_dist,
+                   uint64_t* d_out_label, void* workspace, hipStream_t stream, std::string* err);
 
 // G ascending per-shard lists [G][nq][k] -> [nq][k], the k smallest (dist, label).
 int launch_merge_topk(const float* d_dist, const uint64_t* d_label, uint32_t n_lists, uint32_t nq, uint32_t k,
