@@ -54,7 +54,13 @@ def main() -> None:
     ap.add_argument("--cpu-queries", type=int, default=2000, help="bounded sample of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sharded", action="store_true")
+    ap.add_argument("--workload", choices=("hnsw", "bruteforce"), default="hnsw",
+                    help="hnsw = BASELINE.json configs[1] (the headline metric); bruteforce = configs[2] "
+                         "(exact k-NN 1M x 960 on the MFMA path, its own JSON line)")
+    ap.add_argument("--precision", choices=("fp32", "bf16", "bf16_rerank"), default="bf16_rerank")
     args = ap.parse_args()
+    if args.workload == "bruteforce":
+        return run_bruteforce(args)
 
     import torch
     import torch.distributed as dist
@@ -257,6 +263,92 @@ def main() -> None:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_bruteforce(args) -> None:
+    """BASELINE.json configs[2]: exact brute-force k-NN, 1M x 960 (GIST-like synthetic), 10 000-query
+    batches, k=10, on the MFMA candidate pass + exact re-rank.  One GPU (replicas for N > 1)."""
+    import torch
+
+    from vectordb_amd import datasets
+    from vectordb_amd import index as vi
+
+    if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit("--workload bruteforce is a single-GPU line")
+    dim = 960 if args.dim == 128 else args.dim
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    threads = max(1, min(args.build_threads or int(os.environ.get("OMP_NUM_THREADS", "0")) or 16, 16))
+    t0 = time.time()
+    law = datasets.ClusteredLaw(dim, latent=64)
+    base = law.sample(args.n, seed=1)
+    queries = law.sample(args.nq, seed=2)
+    log(f"data {base.shape} + {queries.shape} in {time.time() - t0:.1f}s")
+    t0 = time.time()
+    bf = vi.BruteforceSearch(vi.L2Space(dim), args.n)
+    bf.add_items(base)
+    bf.to_device(0)
+    log(f"uploaded + prepared (mean, centred f32/bf16 copies, norms) in {time.time() - t0:.1f}s")
+    dq = torch.from_numpy(queries).to(dev)
+    prec = {"fp32": vi.BF_FP32, "bf16": vi.BF_BF16, "bf16_rerank": vi.BF_BF16_RERANK}[args.precision]
+
+    def timed(precision, steps, warmup):
+        for _ in range(warmup):
+            bf.search_batch(dq, args.k, precision=precision)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for a, b in ev:
+            a.record()
+            out = bf.search_batch(dq, args.k, precision=precision)
+            b.record()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, float(np.mean([a.elapsed_time(b) for a, b in ev])), out
+
+    # exact answer (f32 MFMA + exact re-rank + certificate) = ground truth for the bf16 recall
+    el32, ms32, (d32, l32) = timed(vi.BF_FP32, max(1, args.steps // 4), 1)
+    truth = l32.cpu().numpy().view(np.uint64)
+    elapsed, ms, (dd, ll) = timed(prec, args.steps, args.warmup)
+    recall = datasets.recall_at_k(ll.cpu().numpy().view(np.uint64), truth)
+    flops = 2.0 * args.nq * args.n * dim
+    peak = 157.3 if args.precision == "fp32" else 2500.0   # MI355X_MICROARCH.md dense peaks, TFLOP/s
+    achieved = flops / (ms * 1e-3) / 1e12
+    log(f"fp32-exact {ms32:.1f} ms/batch ({flops / (ms32 * 1e-3) / 1e12:.1f} TFLOP/s of 157.3); "
+        f"{args.precision} {ms:.1f} ms/batch, recall@{args.k} vs exact {recall:.4f}")
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        orc.build()
+        ncpu = min(2 * threads, args.nq)
+        ob = orc.OracleBruteforce(orc.L2, dim, args.n, mode=orc.SEQ, o3=True)
+        ob.add(base)
+        r = ob.search(queries[:ncpu], args.k, n_threads=threads)
+        ob.set_mode = None
+        ot = orc.OracleBruteforce(orc.L2, dim, args.n, mode=orc.TREE64, o3=True)
+        ot.add(base)
+        r2 = ot.search(queries[:4], args.k, n_threads=4)
+        same = bool(np.array_equal(r2["label"].astype(np.uint64), truth[:4]) and
+                    np.array_equal(r2["dist"].view(np.uint32), d32.cpu().numpy()[:4].view(np.uint32)))
+        cpu = {"value": round(ncpu / r["seconds"], 2), "unit": "queries/s", "cores": threads, "kind": "port",
+               "sample": f"first {ncpu} queries, full {args.n}x{dim} scan, oracle -O3 sequential-sum arithmetic",
+               "gpu_fp32_bitexact_vs_oracle_on_4": same}
+    out = {
+        "metric": "queries/sec exact brute-force k-NN (1M x 960, k=10)",
+        "value": round(args.nq * args.steps / elapsed, 1), "unit": "queries/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision != "fp32" else "f32",
+        "data": "synthetic",
+        "config": {"workload": f"brute-force k-NN {args.n}x{dim} GIST-like synthetic, {args.nq}-query batch, k={args.k}, "
+                               f"precision {args.precision}", "recall_at_10_vs_exact": round(recall, 4),
+                   "fp32_exact_ms_per_batch": round(ms32, 2),
+                   "fp32_exact_tflops": round(flops / (ms32 * 1e-3) / 1e12, 1)},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(achieved / peak, 4), "traffic": None, "kernel": "bf_gemm_filter (whole step timed: "
+                     "GEMM+filter, compaction, re-rank)", "kernel_ms": round(ms, 3), "algorithmic_flops_per_launch": flops},
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
