@@ -82,16 +82,21 @@ __device__ __forceinline__ float ord2f(uint32_t u) {
     return __builtin_bit_cast(float, (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
 }
 
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int src = lane_id() ^ off;
-        const uint32_t lo = bpermute((uint32_t)v, src);
-        const uint32_t hi = bpermute((uint32_t)(v >> 32), src);
-        const uint64_t o = ((uint64_t)hi << 32) | lo;
-        v = o < v ? o : v;
-    }
-    return v;
+// minimum of v over the 64 lanes, returned wave-uniform: xor butterfly inside each row of 16
+// (DPP), then the four rows through SGPRs
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    uint32_t o;
+    o = dpp_u32<kDppXor1>(v, v);
+    v = o < v ? o : v;
+    o = dpp_u32<kDppXor2>(v, v);
+    v = o < v ? o : v;
+    o = dpp_u32<kDppHalfMirror>(v, v);
+    v = o < v ? o : v;
+    o = dpp_u32<kDppMirror>(v, v);
+    v = o < v ? o : v;
+    const uint32_t a = readlane(v, 0), b = readlane(v, 16), c = readlane(v, 32), d = readlane(v, 48);
+    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
 }
 
 // ------------------------------------------------------------------ distance engine
@@ -99,40 +104,40 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // Scores up to 32 nodes.  In: lane r (< m) holds node id ids[r].  Out: lane r (< m) holds
-// the ordered-u32 distance of node r; other lanes 0xFFFFFFFF.
+// the ordered-u32 distance of node r; the other lanes hold garbage.
 // NCH = number of 64-float chunks per row that are touched; GPB = 16-lane groups whose
 // loads are issued before the first FMA (4 nodes each).
-template <int NCH, int GPB>
+template <int NCH, int GPB, bool IS_L2>
 __device__ __forceinline__ uint32_t score_nodes(const DevGraph& g, const f32x4 (&q)[NCH], uint32_t ids, uint32_t m,
                                                 int lane) {
     const int grp = lane >> 4, t = lane & 15;
     const uint32_t vstride = g.vstride;
-    const bool is_l2 = g.metric == 0;
     uint32_t out = kEmptyWord;
     const uint32_t ngroups = (m + 3u) >> 2;
 #pragma unroll 1
     for (uint32_t base = 0; base < ngroups; base += GPB) {
+        // node ids of every group first (independent cross-lane reads, one wait), then all the
+        // row loads back to back, then the arithmetic
+        uint32_t nid[GPB];
+#pragma unroll
+        for (int b = 0; b < GPB; ++b) nid[b] = bpermute(ids, (int)((4u * (base + b) + (uint32_t)grp) & 63u));
         f32x4 x[GPB][NCH];
 #pragma unroll
         for (int b = 0; b < GPB; ++b) {
 #pragma unroll
             for (int j = 0; j < NCH; ++j) x[b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (base + b < ngroups) {  // wave-uniform
-                const uint32_t r = 4u * (base + b) + (uint32_t)grp;
-                const uint32_t nid = bpermute(ids, (int)(r & 63u));
-                if (r < m) {
-                    const float* row = g.vecs + (size_t)nid * vstride + 4 * t;
+            if (4u * (base + b) + (uint32_t)grp < m) {
+                const float* row = g.vecs + (size_t)nid[b] * vstride + 4 * t;
 #pragma unroll
-                    for (int j = 0; j < NCH; ++j)
-                        if ((uint32_t)(64 * j + 4 * t) < vstride) x[b][j] = *reinterpret_cast<const f32x4*>(row + 64 * j);
-                }
+                for (int j = 0; j < NCH; ++j)
+                    if ((uint32_t)(64 * j + 4 * t) < vstride) x[b][j] = *reinterpret_cast<const f32x4*>(row + 64 * j);
             }
         }
 #pragma unroll
         for (int b = 0; b < GPB; ++b) {
             if (base + b < ngroups) {  // wave-uniform
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                if (is_l2) {
+                if constexpr (IS_L2) {
 #pragma unroll
                     for (int j = 0; j < NCH; ++j) {
                         const float d0 = q[j].x - x[b][j].x, d1 = q[j].y - x[b][j].y;
@@ -157,11 +162,13 @@ __device__ __forceinline__ uint32_t score_nodes(const DevGraph& g, const f32x4 (
                 s = s + dpp_f32<kDppXor2>(s);
                 s = s + dpp_f32<kDppHalfMirror>(s);
                 s = s + dpp_f32<kDppMirror>(s);
-                if (!is_l2) s = 1.0f - s;
-                // node r = 4(base+b)+g lives in group g; hand it to lane r
-                const uint32_t v = bpermute(f2ord(s), 16 * (lane & 3));
-                const uint32_t r = (uint32_t)lane;
-                if ((r >> 2) == base + b && r < m) out = v;
+                if constexpr (!IS_L2) s = 1.0f - s;
+                // node 4(base+b)+g sits in group g: hand it to lane 4(base+b)+g through SGPRs
+                const uint32_t so = f2ord(s);
+                const uint32_t s0 = readlane(so, 0), s1 = readlane(so, 16), s2 = readlane(so, 32), s3 = readlane(so, 48);
+                const uint32_t sel = (uint32_t)lane & 3u;
+                const uint32_t v = sel == 0 ? s0 : (sel == 1 ? s1 : (sel == 2 ? s2 : s3));
+                if (((uint32_t)lane >> 2) == base + b) out = v;
             }
         }
     }
@@ -222,10 +229,11 @@ struct KeyArray {
             if ((idx >> 6) == (uint32_t)r) v = readlane(hi[r], (int)(idx & 63u));
         return v;
     }
-    // Insert (khi, klo); keys are distinct.  Returns the key that fell off the end.
-    __device__ __forceinline__ void insert(uint32_t khi, uint32_t klo, int lane, uint32_t& off_hi, uint32_t& off_lo) {
-        off_hi = readlane(hi[R - 1], 63);
-        off_lo = readlane(lo[R - 1], 63);
+    // Insert (khi, klo); keys are distinct.  (prev_hi, prev_lo) = this lane's last-register key
+    // before the shift: in lane 63 that is the key that fell off the end.
+    __device__ __forceinline__ void insert(uint32_t khi, uint32_t klo, int lane, uint32_t& prev_hi, uint32_t& prev_lo) {
+        prev_hi = hi[R - 1];
+        prev_lo = lo[R - 1];
         uint32_t uh[R], ul[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -257,6 +265,20 @@ struct KeyArray {
             if (idx >= ef && hi[r] != bound_hi) hi[r] = lo[r] = kEmptyWord;
         }
     }
+    // First key with the expanded bit clear, not marked: (id, ordered distance).
+    __device__ __forceinline__ bool peek_candidate(uint32_t& id, uint32_t& dhi) const {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint64_t open = ballot((lo[r] & 1u) == 0u);
+            if (open) {
+                const int p = __builtin_ctzll(open);
+                id = readlane(lo[r], p) >> 1;
+                dhi = readlane(hi[r], p);
+                return true;
+            }
+        }
+        return false;
+    }
     // First key with the expanded bit clear: returns its node id and sets the bit.
     __device__ __forceinline__ bool pop_candidate(int lane, uint32_t& id) {
 #pragma unroll
@@ -287,7 +309,7 @@ struct SearchArgs {
     uint32_t bitmap_words;
 };
 
-template <int NCH, int GPB, int R, bool LARGE>
+template <int NCH, int GPB, int R, bool LARGE, bool IS_L2>
 __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = lane_id();
@@ -346,26 +368,31 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
 
         // ---- entry point and greedy descent, hnsw_core.hpp:1111-1138
         uint32_t cur = g.entry;
-        uint32_t cur_d = readlane(score_nodes<NCH, GPB>(g, q, cur, 1u, lane), 0);
+        uint32_t cur_d = readlane(score_nodes<NCH, GPB, IS_L2>(g, q, cur, 1u, lane), 0);
         ndis += 1;
+        uint32_t cur_row = g.max_level > 0 ? g.upper_row[cur] : 0u;  // first upper list of `cur`
         for (int level = g.max_level; level > 0; --level) {
             bool changed = true;
             while (changed) {
                 changed = false;
-                const uint32_t row = g.upper_row[cur] + (uint32_t)(level - 1);
+                const uint32_t row = cur_row + (uint32_t)(level - 1);
                 const uint32_t nb = (uint32_t)lane < g.ustride ? g.upper_links[(size_t)row * g.ustride + lane] : kNoId;
+                // every neighbour's own list position, fetched beside its vector: no dependent load after the move
+                const uint32_t nb_row = nb != kNoId ? g.upper_row[nb] : 0u;
                 const uint32_t n = (uint32_t)__builtin_popcountll(ballot(nb != kNoId));
                 hops_up += 1;
                 ndis += n;
                 if (n == 0) break;
                 // all n distances are evaluated by the reference too; the scan keeps the
                 // first strict minimum below cur_d
-                const uint32_t d = score_nodes<NCH, GPB>(g, q, nb, n, lane);
-                const uint64_t best = wave_min_u64(((uint64_t)d << 32) | (uint32_t)lane);
-                const uint32_t bd = (uint32_t)(best >> 32);
-                if (bd < cur_d) {
+                uint32_t d = score_nodes<NCH, GPB, IS_L2>(g, q, nb, n, lane);
+                if ((uint32_t)lane >= n) d = kEmptyWord;
+                const uint32_t bd = wave_min_u32(d);
+                if (bd < cur_d) {  // first lane holding the minimum == first strict improvement of the scan
                     cur_d = bd;
-                    cur = readlane(nb, (int)(best & 63u));
+                    const int bl = __builtin_ctzll(ballot(d == bd));
+                    cur = readlane(nb, bl);
+                    cur_row = readlane(nb_row, bl);
                     changed = true;
                 }
             }
@@ -383,6 +410,10 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
         bool overflow = false;
         if (lane == 0) (void)vis.test_and_set(cur);
 
+        // Link rows fetched ahead of need (hints only: a wrong guess costs one 128-B load).
+        //  A: the best unexpanded entry at the time a node's neighbours are being scored;
+        //  B: the best of those neighbours when it beats A - the two nodes the next pop can be.
+        uint32_t pfa_id = kNoId, pfb_id = kNoId, pfa_row = kNoId, pfb_row = kNoId;
         uint32_t cand;
 #pragma unroll 1
         while (arr.pop_candidate(lane, cand)) {
@@ -391,7 +422,10 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
                 overflow = true;
                 break;
             }
-            const uint32_t nb = (uint32_t)lane < g.l0stride ? g.links0[(size_t)cand * g.l0stride + lane] : kNoId;
+            uint32_t nb;
+            if (cand == pfa_id) nb = pfa_row;
+            else if (cand == pfb_id) nb = pfb_row;
+            else nb = (uint32_t)lane < g.l0stride ? g.links0[(size_t)cand * g.l0stride + lane] : kNoId;
             const bool fresh = nb != kNoId && vis.test_and_set(nb);
             const uint64_t fm = ballot(fresh);
             const uint32_t m_all = (uint32_t)__builtin_popcountll(fm);
@@ -404,28 +438,43 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
             const uint32_t dest = fresh ? rank : m_all + ((uint32_t)lane - rank);
             const uint32_t ids_c = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)(fresh ? nb : kNoId));
+            uint32_t peek_d = kEmptyWord;
+            if (arr.peek_candidate(pfa_id, peek_d))
+                pfa_row = (uint32_t)lane < g.l0stride ? g.links0[(size_t)pfa_id * g.l0stride + lane] : kNoId;
+            else
+                pfa_id = kNoId;
 
 #pragma unroll 1
             for (uint32_t c0 = 0; c0 < m_all; c0 += 32) {
                 const uint32_t m = m_all - c0 < 32u ? m_all - c0 : 32u;
                 const uint32_t ids_part = c0 == 0 ? ids_c : bpermute(ids_c, (lane + 32) & 63);
-                const uint32_t dord = score_nodes<NCH, GPB>(g, q, ids_part, m, lane);
+                uint32_t dord = score_nodes<NCH, GPB, IS_L2>(g, q, ids_part, m, lane);
+                if ((uint32_t)lane >= m) dord = kEmptyWord;
+                {
+                    const uint32_t best = wave_min_u32(dord);
+                    if (best < bound && best < peek_d) {
+                        pfb_id = readlane(ids_part, __builtin_ctzll(ballot(dord == best)));
+                        pfb_row = (uint32_t)lane < g.l0stride ? g.links0[(size_t)pfb_id * g.l0stride + lane] : kNoId;
+                    }
+                }
                 // sequential admission in list order with the evolving bound, :339-349
                 uint64_t pend = ballot(dord < bound);
+                bool lost = false;  // lane 63: an unexpanded key at the bound's distance fell off the end
                 while (pend) {
                     const int r = __builtin_ctzll(pend);
                     pend &= pend - 1;
                     const uint32_t d = readlane(dord, r);
                     if (d < bound) {
                         const uint32_t id = readlane(ids_part, r);
-                        uint32_t off_hi, off_lo;
-                        arr.insert(d, id << 1, lane, off_hi, off_lo);
+                        uint32_t prev_hi, prev_lo;
+                        arr.insert(d, id << 1, lane, prev_hi, prev_lo);
                         bound = arr.hi_at(ef - 1);
-                        if (off_hi != kEmptyWord && off_hi == bound && (off_lo & 1u) == 0u) overflow = true;
+                        lost |= lane == 63 && prev_hi != kEmptyWord && prev_hi == bound && (prev_lo & 1u) == 0u;
                         arr.trim(ef, bound, lane);
                         pend &= ballot(dord < bound);
                     }
                 }
+                if (ballot(lost)) overflow = true;
             }
             if (overflow) break;
         }
@@ -511,12 +560,19 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
     const size_t epilogue_bytes = (size_t)64 * R * 12;
     size_t lds_small = (size_t)4 << a.hbits;
     if (lds_small < epilogue_bytes) lds_small = epilogue_bytes;
-    hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, false>), dim3(a.nq), dim3(64), lds_small, stream, a);
+    if (a.g.metric == 0)
+        hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, false, true>), dim3(a.nq), dim3(64), lds_small, stream, a);
+    else
+        hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, false, false>), dim3(a.nq), dim3(64), lds_small, stream, a);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) {
         const uint32_t blocks = a.nq < kLargeBlocks ? a.nq : kLargeBlocks;
-        hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, 2 * R, true>), dim3(blocks), dim3(64), (size_t)64 * 2 * R * 12,
-                           stream, a);
+        if (a.g.metric == 0)
+            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, 2 * R, true, true>), dim3(blocks), dim3(64),
+                               (size_t)64 * 2 * R * 12, stream, a);
+        else
+            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, 2 * R, true, false>), dim3(blocks), dim3(64),
+                               (size_t)64 * 2 * R * 12, stream, a);
         e = hipGetLastError();
     }
     if (e != hipSuccess) {
