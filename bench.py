@@ -232,6 +232,15 @@ def main() -> None:
                "gpu_ids_equal_oracle_on_256": same}
 
     if rank == 0:
+        # HBM-side traffic per launch comes from a separate rocprofv3 --pmc FETCH_SIZE pass of this same
+        # command (counters cannot be read from inside the process); the committed summary is quoted
+        # when the workload is the one it was collected on.
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r1", "hnsw_c2_pmc_fetch_tuned.json")
+        if os.path.exists(pmc) and (args.n, args.dim, args.nq, args.k, args.M, chosen) == (1_000_000, 128, 10_000, 10, 16, 32):
+            with open(pmc) as f:
+                traffic = int(json.load(f)["traffic_bytes_per_launch"])
+            traffic_src = "profiles/r1/hnsw_c2_pmc_fetch_tuned.json (FETCH_SIZE KB x 1024 x 2, gfx950 correction)"
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "queries/sec @ recall@10>=0.95 (1M x 128, k=10)",
@@ -253,8 +262,8 @@ def main() -> None:
                        "mean_ndis": round(float(st[:, 0].mean()), 1), "mean_hops": round(float(st[:, 1].mean()), 1),
                        "build_seconds_host": round(build_s, 1), "build_threads": threads},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "hnsw_search_kernel", "kernel_ms": round(kern_ms, 4),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src, "kernel": "hnsw_search_kernel", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
         }

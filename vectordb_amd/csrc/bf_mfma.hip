@@ -112,7 +112,10 @@ __global__ __launch_bounds__(256) void bf_center(const float* x, uint32_t n, uin
     if (lane == 0) {
         nx[row] = (float)s;
         const float norm = (float)__builtin_sqrt(s) * 1.0000002f;  // round up: it feeds an error BOUND
-        atomicMax(reinterpret_cast<uint32_t*>(stats), __builtin_bit_cast(uint32_t, norm));
+        // one hot word for every row of the table: only rows that raise the maximum touch it
+        const uint32_t nb = __builtin_bit_cast(uint32_t, norm);
+        uint32_t* mx = reinterpret_cast<uint32_t*>(stats);
+        if (nb > __hip_atomic_load(mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(mx, nb);
     }
 }
 

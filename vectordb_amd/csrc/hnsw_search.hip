@@ -107,6 +107,38 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // the ordered-u32 distance of node r; the other lanes hold garbage.
 // NCH = number of 64-float chunks per row that are touched; GPB = 16-lane groups whose
 // loads are issued before the first FMA (4 nodes each).
+template <int NCH, bool IS_L2>
+__device__ __forceinline__ uint32_t group_distance(const f32x4 (&q)[NCH], const f32x4 (&x)[NCH]) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if constexpr (IS_L2) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const float d0 = q[j].x - x[j].x, d1 = q[j].y - x[j].y;
+            const float d2 = q[j].z - x[j].z, d3 = q[j].w - x[j].w;
+            a0 = __builtin_fmaf(d0, d0, a0);
+            a1 = __builtin_fmaf(d1, d1, a1);
+            a2 = __builtin_fmaf(d2, d2, a2);
+            a3 = __builtin_fmaf(d3, d3, a3);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            a0 = __builtin_fmaf(q[j].x, x[j].x, a0);
+            a1 = __builtin_fmaf(q[j].y, x[j].y, a1);
+            a2 = __builtin_fmaf(q[j].z, x[j].z, a2);
+            a3 = __builtin_fmaf(q[j].w, x[j].w, a3);
+        }
+    }
+    // pairwise tree over the 64 virtual lanes: 2 levels in-lane, 4 across lanes
+    float s = (a0 + a1) + (a2 + a3);
+    s = s + dpp_f32<kDppXor1>(s);
+    s = s + dpp_f32<kDppXor2>(s);
+    s = s + dpp_f32<kDppHalfMirror>(s);
+    s = s + dpp_f32<kDppMirror>(s);
+    if constexpr (!IS_L2) s = 1.0f - s;
+    return f2ord(s);
+}
+
 template <int NCH, int GPB, bool IS_L2>
 __device__ __forceinline__ uint32_t score_nodes(const DevGraph& g, const f32x4 (&q)[NCH], uint32_t ids, uint32_t m,
                                                 int lane) {
@@ -133,44 +165,19 @@ __device__ __forceinline__ uint32_t score_nodes(const DevGraph& g, const f32x4 (
                     if ((uint32_t)(64 * j + 4 * t) < vstride) x[b][j] = *reinterpret_cast<const f32x4*>(row + 64 * j);
             }
         }
+        // Group b's result (the same in its 16 lanes) is kept by lane t == b of each group ...
+        uint32_t keep = kEmptyWord;
 #pragma unroll
         for (int b = 0; b < GPB; ++b) {
             if (base + b < ngroups) {  // wave-uniform
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                if constexpr (IS_L2) {
-#pragma unroll
-                    for (int j = 0; j < NCH; ++j) {
-                        const float d0 = q[j].x - x[b][j].x, d1 = q[j].y - x[b][j].y;
-                        const float d2 = q[j].z - x[b][j].z, d3 = q[j].w - x[b][j].w;
-                        a0 = __builtin_fmaf(d0, d0, a0);
-                        a1 = __builtin_fmaf(d1, d1, a1);
-                        a2 = __builtin_fmaf(d2, d2, a2);
-                        a3 = __builtin_fmaf(d3, d3, a3);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NCH; ++j) {
-                        a0 = __builtin_fmaf(q[j].x, x[b][j].x, a0);
-                        a1 = __builtin_fmaf(q[j].y, x[b][j].y, a1);
-                        a2 = __builtin_fmaf(q[j].z, x[b][j].z, a2);
-                        a3 = __builtin_fmaf(q[j].w, x[b][j].w, a3);
-                    }
-                }
-                // pairwise tree over the 64 virtual lanes: 2 levels in-lane, 4 across lanes
-                float s = (a0 + a1) + (a2 + a3);
-                s = s + dpp_f32<kDppXor1>(s);
-                s = s + dpp_f32<kDppXor2>(s);
-                s = s + dpp_f32<kDppHalfMirror>(s);
-                s = s + dpp_f32<kDppMirror>(s);
-                if constexpr (!IS_L2) s = 1.0f - s;
-                // node 4(base+b)+g sits in group g: hand it to lane 4(base+b)+g through SGPRs
-                const uint32_t so = f2ord(s);
-                const uint32_t s0 = readlane(so, 0), s1 = readlane(so, 16), s2 = readlane(so, 32), s3 = readlane(so, 48);
-                const uint32_t sel = (uint32_t)lane & 3u;
-                const uint32_t v = sel == 0 ? s0 : (sel == 1 ? s1 : (sel == 2 ? s2 : s3));
-                if (((uint32_t)lane >> 2) == base + b) out = v;
+                const uint32_t so0 = group_distance<NCH, IS_L2>(q, x[b]);
+                if (t == b) keep = so0;
             }
         }
+        // ... and node r = 4 (base + b) + g is handed to lane r in one cross-lane read
+        const uint32_t rl = (uint32_t)lane - 4u * base;  // r relative to this batch
+        const uint32_t v = bpermute(keep, (int)((16u * (rl & 3u) + (rl >> 2)) & 63u));
+        if (rl < 4u * GPB) out = v;
     }
     return out;
 }
@@ -188,12 +195,12 @@ struct LdsVisited {
     __device__ __forceinline__ bool test_and_set(uint32_t id) {
         const uint32_t mask = (1u << hbits) - 1u;
         uint32_t s = (id * 0x9E3779B1u) >> (32u - hbits);
-        for (;;) {
-            const uint32_t old = atomicCAS(&tab[s], kEmptyWord, id);
-            if (old == kEmptyWord) return true;
-            if (old == id) return false;
+        uint32_t old = atomicCAS(&tab[s], kEmptyWord, id);  // almost always decides
+        while (old != kEmptyWord && old != id) {
             s = (s + 1u) & mask;
+            old = atomicCAS(&tab[s], kEmptyWord, id);
         }
+        return old == kEmptyWord;
     }
     __device__ __forceinline__ uint32_t limit() const { return (3u << hbits) >> 2; }  // 75 % fill
 };
