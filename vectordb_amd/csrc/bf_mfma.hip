@@ -26,6 +26,7 @@
 
 #include <cstdint>
 #include <string>
+#include <type_traits>
 
 #include "bf_internal.hpp"
 #include "device_index.hpp"
@@ -177,119 +178,172 @@ struct GemmArgs {
     const float* off;
     int32_t metric;
     uint32_t row_lo, row_hi, nq, cap;
+    uint32_t tiles_r, tiles_q;  // 128-row base tiles of the slab, 128-query tiles
     uint32_t* count;
     const uint32_t* tauhat;  // [nq] ordered-u32 threshold on the approximate distance
     uint64_t* entries;       // [nq][cap]  ord(approx dist) << 32 | row
 };
 
-constexpr int kLdw = 36;  // LDS row stride in 4-byte words: 128 B of data + 16 B pad (conflict-free b128)
+// LDS image of one operand tile of one k-step: 256 rows x 64 B, no padding (LDS-DMA writes 1 KiB
+// pieces linearly: 16 rows per wave instruction), 16-B chunk c of row r stored at chunk position
+// c ^ ((r >> 2) & 3).  A ds_read_b128 lane group (16 consecutive rows, or the hardware's
+// {0-3,12-15,20-27} pattern) then hits 16 distinct 16-B slots of the 256-B bank row.
+constexpr int kTile = 256;                    // base rows and queries per block
+constexpr int kRowB = 64;                     // bytes per row per k-step: 32 bf16 or 16 f32
+constexpr int kTileBytes = kTile * kRowB;     // one operand tile of one k-step (16 KiB)
+constexpr int kStageBytes = 2 * kTileBytes;   // A tile + B tile
+constexpr int kStages = 4;                    // ring of k-steps in LDS: 3 in flight behind the one computed
+constexpr int kGemmThreads = 512;             // 8 waves: 2 (rows) x 4 (queries), 128 x 64 outputs each
+constexpr int kPiecesPerWave = 4;             // 32 pieces (16 A + 16 B) per k-step over 8 waves
 
 template <bool BF16>
-__global__ __launch_bounds__(256) void bf_gemm_filter(GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t As[128 * kLdw];
-    __shared__ __attribute__((aligned(16))) uint32_t Bs[128 * kLdw];
-    __shared__ float nx_s[128];
+__global__ __launch_bounds__(kGemmThreads) void bf_gemm_filter(GemmArgs a) {
+    // one LDS object: the ring + the tile's row norms (a second __shared__ array beside an LDS-DMA
+    // target makes hipcc drain the DMA before every LDS read)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kStages * kStageBytes + kTile * 4];
+    float* nx_s = reinterpret_cast<float*>(smem + kStages * kStageBytes);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1, h = lane >> 5, li = lane & 31;
-    const uint32_t row0 = a.row_lo + blockIdx.x * 128u, q0 = blockIdx.y * 128u;
+    const int wr = wave >> 2, wc = wave & 3, h = lane >> 5, li = lane & 31;
+    // Block -> tile map.  Blocks are dealt round-robin over the 8 XCDs (block b and b + 8 share an
+    // L2, 32 CUs).  The 32 blocks an XCD runs at one time form a super-tile of 4 base tiles x 8
+    // query tiles that advance through K together, so per k-step the XCD pulls 12 operand slices
+    // through its L2 for 32 blocks' worth of demand (a row of 32 query tiles would pull 33).
+    const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+    const uint32_t sup = (idx >> 5) * 8u + xcd, in = idx & 31u;  // super-tile, position inside it
+    const uint32_t sup_q = (a.tiles_q + 7u) >> 3;                // super-tiles per row of super-tiles
+    const uint32_t tr = (sup / sup_q) * 4u + (in >> 3), tq = (sup % sup_q) * 8u + (in & 7u);
+    if (tr >= a.tiles_r || tq >= a.tiles_q) return;              // ragged edge of the super-tile grid
+    const uint32_t row0 = a.row_lo + tr * kTile, q0 = tq * kTile;
     const size_t row_bytes = (size_t)a.ld * (BF16 ? 2 : 4);
     const char* Ab = static_cast<const char*>(a.A);
     const char* Bb = static_cast<const char*>(a.B);
 
-    if (tid < 128) nx_s[tid] = row0 + tid < a.row_hi ? a.nx[row0 + tid] : 0.f;
+    if (tid < kTile) nx_s[tid] = row0 + tid < a.row_hi ? a.nx[row0 + tid] : 0.f;
 
-    uint4 ra[4], rb[4];
-    auto gload = [&](uint32_t ks) {
+    // global -> LDS, no registers: each wave moves 4 pieces of 1 KiB (16 rows x 64 B) per k-step.
+    // Rows past the end of the slab / batch re-read the last valid row (their products only reach
+    // output elements that the epilogue drops): every wave issues exactly 4 DMA instructions per
+    // k-step, which is what the counted waits below rely on.
+    const char* src[kPiecesPerWave];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + i * 256, r = idx >> 3, c = idx & 7;
-            const uint32_t row = row0 + r, q = q0 + r;
-            ra[i] = make_uint4(0u, 0u, 0u, 0u);
-            rb[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (row < a.row_hi) ra[i] = *reinterpret_cast<const uint4*>(Ab + (size_t)row * row_bytes + (size_t)ks * 128 + c * 16);
-            if (q < a.nq) rb[i] = *reinterpret_cast<const uint4*>(Bb + (size_t)q * row_bytes + (size_t)ks * 128 + c * 16);
-        }
-    };
-    auto lstore = [&]() {
+    for (int i = 0; i < kPiecesPerWave; ++i) {
+        const int piece = wave * kPiecesPerWave + i;  // 0..15: A, 16..31: B   (wave-uniform)
+        const bool isA = piece < 16;
+        const int rin = (piece & 15) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((rin >> 2) & 3);
+        uint32_t grow = (isA ? row0 : q0) + (uint32_t)rin;
+        const uint32_t last = (isA ? a.row_hi : a.nq) - 1u;
+        grow = grow < last ? grow : last;
+        src[i] = (isA ? Ab : Bb) + (size_t)grow * row_bytes + c * 16;
+    }
+    uint32_t issued = 0;  // k-steps handed to the DMA so far
+    auto stage = [&](int slot) {
+        // past the last k-step: re-read the last one (never computed; keeps the DMA count uniform)
+        const int back = issued < a.ksteps ? 0 : kRowB;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + i * 256, r = idx >> 3, c = idx & 7;
-            *reinterpret_cast<uint4*>(&As[r * kLdw + c * 4]) = ra[i];
-            *reinterpret_cast<uint4*>(&Bs[r * kLdw + c * 4]) = rb[i];
+        for (int i = 0; i < kPiecesPerWave; ++i) {
+            const int piece = wave * kPiecesPerWave + i;
+            unsigned char* dst = smem + slot * kStageBytes + (piece < 16 ? 0 : kTileBytes) + (piece & 15) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] - back),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            if (back == 0) src[i] += kRowB;
         }
+        issued += 1;
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    gload(0);
-    for (uint32_t ks = 0; ks < a.ksteps; ++ks) {
-        __syncthreads();
-        lstore();
-        __syncthreads();
-        if (ks + 1 < a.ksteps) gload(ks + 1);
-        const uint32_t* arow[2] = {&As[(wr * 64 + li) * kLdw], &As[(wr * 64 + 32 + li) * kLdw]};
-        const uint32_t* brow[2] = {&Bs[(wc * 64 + li) * kLdw], &Bs[(wc * 64 + 32 + li) * kLdw]};
+    const int swz = (li >> 2) & 3;  // (row >> 2) & 3 of every row this lane reads (rows li, li+32, ...)
+    using frag_t = typename std::conditional<BF16, bf16x8, f32x4>::type;
+    // fragments of k-block s (bf16: 16 k, f32: 4 k-pairs) of one stage: two blocks per stage.
+    // bf16: lane half h owns k = 16 s + 8 h .. +7; f32: k = 8 h + 4 s .. +3 (A and B alike).
+    auto load_frags = [&](int slot, int s, frag_t (&af)[4], frag_t (&bfr)[2]) {
+        const int pos = (((BF16 ? 2 * s + h : 2 * h + s)) ^ swz) * 16;
+        const unsigned char* At = smem + slot * kStageBytes + (wr * 128 + li) * kRowB + pos;
+        const unsigned char* Bt = smem + slot * kStageBytes + kTileBytes + (wc * 64 + li) * kRowB + pos;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const frag_t*>(At + m * 32 * kRowB);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bfr[n] = *reinterpret_cast<const frag_t*>(Bt + n * 32 * kRowB);
+    };
+    auto mma = [&](const frag_t (&af)[4], const frag_t (&bfr)[2]) {
         if constexpr (BF16) {
-            // 64 bf16 per row per step = 4 MFMA k-blocks of 16; lane half h owns k = 16 s + 8 h .. +7
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                bf16x8 af[2], bfr[2];
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int m = 0; m < 2; ++m) af[m] = *reinterpret_cast<const bf16x8*>(arow[m] + s * 8 + h * 4);
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+        } else {
 #pragma unroll
-                for (int n = 0; n < 2; ++n) bfr[n] = *reinterpret_cast<const bf16x8*>(brow[n] + s * 8 + h * 4);
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
-            }
-        } else {
-            // 32 f32 per row per step; lane half h owns k = 16 h .. 16 h + 15 (A and B alike)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4 af[2], bfr[2];
-#pragma unroll
-                for (int m = 0; m < 2; ++m) af[m] = *reinterpret_cast<const f32x4*>(arow[m] + h * 16 + j * 4);
-#pragma unroll
-                for (int n = 0; n < 2; ++n) bfr[n] = *reinterpret_cast<const f32x4*>(brow[n] + h * 16 + j * 4);
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-#pragma unroll
-                        for (int n = 0; n < 2; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][c], bfr[n][c], acc[m][n], 0, 0, 0);
-            }
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][c], bfr[n][c], acc[m][n], 0, 0, 0);
         }
-    }
+    };
 
-    // epilogue: column = query (lane & 31), registers = base rows
+    // Ring protocol.  Iteration ks computes slot ks % 4 while the DMA of steps ks+1 .. ks+3 is in
+    // flight.  A wave's DMA instructions retire in order, so `vmcnt(8)` at the end of iteration ks
+    // means its pieces of step ks+1 have landed (the 8 youngest = steps ks+2, ks+3 may still fly);
+    // the barrier then makes that true for every wave, and also says every wave is done reading
+    // slot ks % 4, which the next iteration refills with step ks+4.  Steps past the end are issued
+    // as re-reads of the last step (cheap, keeps the counts uniform) and never computed.
+    const uint32_t nk = a.ksteps;
+    for (int p = 0; p < kStages - 1; ++p) stage(p);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // Fragment reads run one k-block ahead of the MFMAs that consume them (two register sets), so
+    // the LDS latency hides behind 8 (bf16) / 32 (f32) MFMAs instead of stalling every group of 4.
+    // The sched_barriers pin that order: left alone, hipcc sinks the reads next to their use and
+    // recycles one register set.
+    frag_t a0[4], b0[2], a1[4], b1[2];
+    load_frags(0, 0, a0, b0);
+    for (uint32_t ks = 0; ks < nk; ++ks) {
+        const int slot = (int)(ks & (kStages - 1));
+        stage((int)((ks + kStages - 1) & (kStages - 1)));
+        load_frags(slot, 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // slot + 1 always holds landed data (past the end: the re-read of the last step)
+        load_frags((slot + 1) & (kStages - 1), 0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the over-issued steps before LDS is released
+
+    // epilogue: column = query (lane & 31), registers = base rows.  approx dist = (nx - 2 dot) + off;
+    // pairs at or below the query's running threshold are appended to its candidate buffer.
     const bool is_l2 = a.metric == 0;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const uint32_t q = q0 + wc * 64 + n * 32 + li;
         const bool qok = q < a.nq;
-        const uint32_t tauh = qok ? a.tauhat[q] : 0u;
+        const float tauf = qok ? ord2f(a.tauhat[q]) : -__builtin_inff();   // all-ones decodes to NaN: handled below
+        const bool open = qok && a.tauhat[q] == 0xFFFFFFFFu;               // no threshold yet: everything passes
         const float offq = qok ? a.off[q] : 0.f;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < 4; ++m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rin = wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int rin = wr * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const uint32_t row = row0 + rin;
                 const float dot = acc[m][n][r];
-                const float s = is_l2 ? nx_s[rin] - 2.0f * dot : -dot;
-                const uint32_t od = f2ord(s + offq);
-                if (qok && row < a.row_hi && od <= tauh) {
+                const float dh = (is_l2 ? nx_s[rin] - 2.0f * dot : -dot) + offq;
+                if (qok && row < a.row_hi && (open || dh <= tauf)) {
                     const uint32_t pos = atomicAdd(&a.count[q], 1u);
-                    if (pos < a.cap) a.entries[(size_t)q * a.cap + pos] = ((uint64_t)od << 32) | row;
+                    if (pos < a.cap) a.entries[(size_t)q * a.cap + pos] = ((uint64_t)f2ord(dh) << 32) | row;
                 }
             }
         }
@@ -448,7 +502,7 @@ int launch_bf_mfma(const BfDeviceData& d, int precision, const float* d_queries,
     g.A = bf16 ? static_cast<const void*>(d.xb) : static_cast<const void*>(d.xc);
     g.B = bf16 ? static_cast<const void*>(qb) : static_cast<const void*>(qf);
     g.ld = bf16 ? d.kp64 : d.vstride;
-    g.ksteps = bf16 ? d.kp64 / 64 : d.vstride / 32;
+    g.ksteps = bf16 ? d.kp64 / 32 : d.vstride / 16;  // 64 B of every row per k-step
     g.nx = d.nx;
     g.off = off;
     g.metric = d.metric;
@@ -474,13 +528,17 @@ int launch_bf_mfma(const BfDeviceData& d, int precision, const float* d_queries,
     uint32_t lo = 0;
     while (lo < d.n) {
         uint32_t slab = lo == 0 ? kBfMfmaCap - kprime : (lo < kBfMaxSlab ? lo : kBfMaxSlab);
-        slab = slab / 128 * 128;
+        slab = slab / kTile * kTile;
         const uint32_t hi = d.n - lo > slab ? lo + slab : d.n;
         g.row_lo = lo;
         g.row_hi = hi;
-        const dim3 grid((hi - lo + 127) / 128, (nq + 127) / 128);
-        if (bf16) hipLaunchKernelGGL((bf_gemm_filter<true>), grid, dim3(256), 0, stream, g);
-        else hipLaunchKernelGGL((bf_gemm_filter<false>), grid, dim3(256), 0, stream, g);
+        g.tiles_r = (hi - lo + kTile - 1) / kTile;
+        g.tiles_q = (nq + kTile - 1) / kTile;
+        // super-tiles of 4 x 8 tiles, dealt to the 8 XCDs in turn (see the kernel's block -> tile map)
+        const uint32_t n_sup = ((g.tiles_r + 3) / 4) * ((g.tiles_q + 7) / 8);
+        const dim3 grid(((n_sup + 7) / 8) * 8 * 32);
+        if (bf16) hipLaunchKernelGGL((bf_gemm_filter<true>), grid, dim3(kGemmThreads), 0, stream, g);
+        else hipLaunchKernelGGL((bf_gemm_filter<false>), grid, dim3(kGemmThreads), 0, stream, g);
         e = hipGetLastError();
         if (e == hipSuccess) e = enqueue_bf_compact(c, stream);
         if (e != hipSuccess) break;
