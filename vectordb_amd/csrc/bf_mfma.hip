@@ -8,12 +8,15 @@
 //   prepare (vdb_bf_to_device)   mean vector mu, centred copies xc = x - mu in f32 and bf16,
 //                                ||xc||^2 per row.  Centring leaves L2 distances unchanged and
 //                                shifts inner products by a per-query constant, and makes the
-//                                f32/bf16 products an order of magnitude more accurate.
-//   bf_prep_queries              qc = q - mu (L2) / q (IP), per-query offset and error bound.
-//   bf_gemm_filter<BF16>         128 base rows x 128 queries per block, 4 waves of 64x64,
-//                                v_mfma_f32_32x32x2_f32 or v_mfma_f32_32x32x16_bf16; the epilogue
-//                                turns dots into approximate distances and appends the pairs
-//                                that beat the query's running threshold to its candidate buffer.
+//                                f32/bf16 products an order of magnitude more accurate.  The
+//                                copies are stored as PANELS (below), not row-major.
+//   bf_prep_queries              qc = q - mu (L2) / q (IP) in the same panel layout, per-query
+//                                offset and error bound.
+//   bf_gemm_filter<BF16>         256 base rows x 256 queries per block, 8 waves of 128x64,
+//                                v_mfma_f32_32x32x2_f32 or v_mfma_f32_32x32x16_bf16, operands
+//                                staged by LDS-DMA through a 4-deep ring; the epilogue turns
+//                                dots into approximate distances and appends the pairs that
+//                                beat the query's running threshold to its candidate buffer.
 //   bf_compact (bf_search.hip)   keeps the k' best approximate candidates, publishes the
 //                                threshold for the next slab of base rows.
 //   bf_rerank                    exact tree64 distances of the k' survivors (the oracle's
@@ -22,6 +25,15 @@
 //   bf_compact (final)           exact top-k by (dist, label); a query whose k-th exact distance
 //                                is not below its certificate is re-run by the exact scan, so
 //                                VDB_BF_FP32 results equal the CPU path bit for bit.
+//
+// Panel layout of a GEMM operand (centred base rows, prepared queries): rows in tiles of 256, the
+// K axis in steps of 64 B (16 f32 / 32 bf16); element (row, c) of step s = c / per_step lives at
+//   (((row / 256) * ksteps + s) * 256 + row % 256) * 64 B + (c % per_step) * sizeof(elt)
+// so the 256 x 64 B slice a block stages per k-step is 16 KiB of CONTIGUOUS memory and every
+// LDS-DMA instruction (1 KiB) reads eight whole 128-B cache lines.  Row-major operands made each
+// instruction touch sixteen lines and use half of each; the vector cache's line rate, not L2 or
+// HBM bandwidth, then capped the staging at ~37 GB/s per CU (measured with the loads pinned to
+// one hot k-step).  Rows up to the next multiple of 256 exist and hold zeros.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -56,6 +68,14 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
+}
+
+// element index of (row, column c) in the panel layout (see the file header)
+__device__ __forceinline__ size_t panel_f32(uint32_t row, uint32_t c, uint32_t ksteps) {
+    return ((((size_t)(row >> 8) * ksteps + (c >> 4)) * 256u + (row & 255u)) << 4) + (c & 15u);
+}
+__device__ __forceinline__ size_t panel_bf16(uint32_t row, uint32_t c, uint32_t ksteps) {
+    return ((((size_t)(row >> 8) * ksteps + (c >> 5)) * 256u + (row & 255u)) << 5) + (c & 31u);
 }
 
 // ------------------------------------------------------------------ index preparation
@@ -95,20 +115,25 @@ __global__ __launch_bounds__(256) void bf_colsum_final(const double* partial, ui
     }
 }
 
-// one wave per row: xc = x - mu (f32), bf16(xc), ||xc||^2, running max of ||xc||
+// one wave per row of the padded table: xc = x - mu (f32 panels), bf16(xc) (bf16 panels), ||xc||^2,
+// running max of ||xc||; rows n .. round_up(n, 256) are written as zeros
 __global__ __launch_bounds__(256) void bf_center(const float* x, uint32_t n, uint32_t dim, uint32_t vstride, uint32_t kp64,
                                                  const float* mu, float* xc, __bf16* xb, float* nx, float* stats) {
     const int lane = threadIdx.x & 63;
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n) return;
+    const uint32_t npad = (n + 255u) & ~255u;
+    if (row >= npad) return;
+    const bool real = row < n;
+    const uint32_t ksf = vstride >> 4, ksb = kp64 >> 5;
     double s = 0.0;
     for (uint32_t c = lane; c < kp64; c += 64) {
         float v = 0.f;
-        if (c < dim) v = x[(size_t)row * vstride + c] - mu[c];
-        if (c < vstride) xc[(size_t)row * vstride + c] = v;
-        xb[(size_t)row * kp64 + c] = (__bf16)v;
+        if (real && c < dim) v = x[(size_t)row * vstride + c] - mu[c];
+        if (c < vstride) xc[panel_f32(row, c, ksf)] = v;
+        xb[panel_bf16(row, c, ksb)] = (__bf16)v;
         s += (double)v * (double)v;
     }
+    if (!real) return;
     s = wave_sum(s);
     if (lane == 0) {
         nx[row] = (float)s;
@@ -128,8 +153,8 @@ struct QPrepArgs {
     int32_t metric;
     const float* mu;
     const float* stats;  // [0] max ||xc||, [1] ||mu||
-    float* qf;           // [nq][vstride]
-    __bf16* qb;          // [nq][kp64]
+    float* qf;           // f32 panels, round_up(nq, 256) rows
+    __bf16* qb;          // bf16 panels, round_up(nq, 256) rows
     float* off;          // [nq]  dist ~= score + off
     float* eps;          // [nq]  |approx dist - exact tree64 dist| <= eps  (f32 pass)
 };
@@ -137,20 +162,24 @@ struct QPrepArgs {
 __global__ __launch_bounds__(256) void bf_prep_queries(QPrepArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= a.nq) return;
+    const uint32_t nqpad = (a.nq + 255u) & ~255u;
+    if (q >= nqpad) return;
+    const bool real = q < a.nq;
     const bool is_l2 = a.metric == 0;
+    const uint32_t ksf = a.vstride >> 4, ksb = a.kp64 >> 5;
     double sq = 0.0, qmu = 0.0;
     for (uint32_t c = lane; c < a.kp64; c += 64) {
         float v = 0.f;
-        if (c < a.dim) {
+        if (real && c < a.dim) {
             const float raw = a.queries[(size_t)q * a.dim + c];
             v = is_l2 ? raw - a.mu[c] : raw;
             qmu += (double)raw * (double)a.mu[c];
         }
-        if (c < a.vstride) a.qf[(size_t)q * a.vstride + c] = v;
-        a.qb[(size_t)q * a.kp64 + c] = (__bf16)v;
+        if (c < a.vstride) a.qf[panel_f32(q, c, ksf)] = v;
+        a.qb[panel_bf16(q, c, ksb)] = (__bf16)v;
         sq += (double)v * (double)v;
     }
+    if (!real) return;
     sq = wave_sum(sq);
     qmu = wave_sum(qmu);
     if (lane == 0) {
@@ -170,17 +199,16 @@ __global__ __launch_bounds__(256) void bf_prep_queries(QPrepArgs a) {
 // ------------------------------------------------------------------ GEMM + filter
 
 struct GemmArgs {
-    const void* A;  // centred base rows, f32 [n][ld] or bf16 [n][ld]
-    const void* B;  // prepared queries, same element type and row length
-    uint32_t ld;    // elements per row
-    uint32_t ksteps;
-    const float* nx;
-    const float* off;
+    const void* A;    // centred base rows, f32 or bf16 panels (file header)
+    const void* B;    // prepared queries, same element type and layout
+    uint32_t ksteps;  // 64 B of every row per k-step
+    const float* nx;  // ||xc||^2, padded with zeros to a multiple of 256 rows
+    const float* off;        // [round_up(nq, 256)]
     int32_t metric;
-    uint32_t row_lo, row_hi, nq, cap;
-    uint32_t tiles_r, tiles_q;  // 128-row base tiles of the slab, 128-query tiles
+    uint32_t row_lo, row_hi, nq, cap;  // row_lo is a multiple of 256
+    uint32_t tiles_r, tiles_q;         // 256-row base tiles of the slab, 256-query tiles
     uint32_t* count;
-    const uint32_t* tauhat;  // [nq] ordered-u32 threshold on the approximate distance
+    const uint32_t* tauhat;  // [round_up(nq, 256)] ordered-u32 threshold on the approximate distance
     uint64_t* entries;       // [nq][cap]  ord(approx dist) << 32 | row
 };
 
@@ -188,77 +216,103 @@ struct GemmArgs {
 // pieces linearly: 16 rows per wave instruction), 16-B chunk c of row r stored at chunk position
 // c ^ ((r >> 2) & 3).  A ds_read_b128 lane group (16 consecutive rows, or the hardware's
 // {0-3,12-15,20-27} pattern) then hits 16 distinct 16-B slots of the 256-B bank row.
-constexpr int kTile = 256;                    // base rows and queries per block
+constexpr int kTile = 256;                    // base rows and queries per tile
 constexpr int kRowB = 64;                     // bytes per row per k-step: 32 bf16 or 16 f32
 constexpr int kTileBytes = kTile * kRowB;     // one operand tile of one k-step (16 KiB)
 constexpr int kStageBytes = 2 * kTileBytes;   // A tile + B tile
 constexpr int kStages = 4;                    // ring of k-steps in LDS: 3 in flight behind the one computed
+constexpr int kAuxBytes = 3 * 1024;           // per tile: 256 x (||xc||^2, tau_hat, query offset)
 constexpr int kGemmThreads = 512;             // 8 waves: 2 (rows) x 4 (queries), 128 x 64 outputs each
+constexpr int kGemmBlocks = 256;              // persistent: one block per CU (LDS admits no second)
 constexpr int kPiecesPerWave = 4;             // 32 pieces (16 A + 16 B) per k-step over 8 waves
 
+// Persistent tile loop.  Block b sits on XCD b % 8 (round-robin dispatch; placement is speed, not
+// correctness) at position b / 8 of a super-tile of 4 base tiles x 8 query tiles; the 32 blocks of
+// an XCD walk the same super-tiles (s = xcd, xcd + 8, ...) and advance through K together, so per
+// k-step the XCD pulls 12 operand slices through its L2 for 32 blocks' worth of demand.
+//
+// The k-steps of ALL of a block's tiles form one stream through the LDS ring: while the last steps
+// of a tile are computed the DMA already fetches the first steps of the next, and the epilogue
+// (filter + append) runs with those loads in flight.  With one block per tile the pipeline fill,
+// the block launch and a scalar epilogue cost more than the K loop itself (17 us against 15 us per
+// tile at d = 960, measured by emptying the loop).
 template <bool BF16>
 __global__ __launch_bounds__(kGemmThreads) void bf_gemm_filter(GemmArgs a) {
-    // one LDS object: the ring + the tile's row norms (a second __shared__ array beside an LDS-DMA
-    // target makes hipcc drain the DMA before every LDS read)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[kStages * kStageBytes + kTile * 4];
-    float* nx_s = reinterpret_cast<float*>(smem + kStages * kStageBytes);
+    // one LDS object: the ring + four tiles' worth of epilogue inputs (a second __shared__ array
+    // beside an LDS-DMA target makes hipcc drain the DMA before every LDS read)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kStages * kStageBytes + 4 * kAuxBytes];
+    unsigned char* aux_s = smem + kStages * kStageBytes;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3, h = lane >> 5, li = lane & 31;
-    // Block -> tile map.  Blocks are dealt round-robin over the 8 XCDs (block b and b + 8 share an
-    // L2, 32 CUs).  The 32 blocks an XCD runs at one time form a super-tile of 4 base tiles x 8
-    // query tiles that advance through K together, so per k-step the XCD pulls 12 operand slices
-    // through its L2 for 32 blocks' worth of demand (a row of 32 query tiles would pull 33).
-    const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
-    const uint32_t sup = (idx >> 5) * 8u + xcd, in = idx & 31u;  // super-tile, position inside it
-    const uint32_t sup_q = (a.tiles_q + 7u) >> 3;                // super-tiles per row of super-tiles
-    const uint32_t tr = (sup / sup_q) * 4u + (in >> 3), tq = (sup % sup_q) * 8u + (in & 7u);
-    if (tr >= a.tiles_r || tq >= a.tiles_q) return;              // ragged edge of the super-tile grid
-    const uint32_t row0 = a.row_lo + tr * kTile, q0 = tq * kTile;
-    const size_t row_bytes = (size_t)a.ld * (BF16 ? 2 : 4);
-    const char* Ab = static_cast<const char*>(a.A);
-    const char* Bb = static_cast<const char*>(a.B);
+    const uint32_t xcd = blockIdx.x & 7u, in = blockIdx.x >> 3;
+    const uint32_t sup_q = (a.tiles_q + 7u) >> 3, n_sup = sup_q * ((a.tiles_r + 3u) >> 2);
+    // first super-tile s' >= s of this XCD in which this block's position holds a tile (ragged edges)
+    auto next_tile = [&](uint32_t s, uint32_t& tr, uint32_t& tq) {
+        for (; s < n_sup; s += 8u) {
+            tr = (s / sup_q) * 4u + (in >> 3);
+            tq = (s % sup_q) * 8u + (in & 7u);
+            if (tr < a.tiles_r && tq < a.tiles_q) break;
+        }
+        return s;
+    };
 
-    if (tid < kTile) nx_s[tid] = row0 + tid < a.row_hi ? a.nx[row0 + tid] : 0.f;
-
-    // global -> LDS, no registers: each wave moves 4 pieces of 1 KiB (16 rows x 64 B) per k-step.
-    // Rows past the end of the slab / batch re-read the last valid row (their products only reach
-    // output elements that the epilogue drops): every wave issues exactly 4 DMA instructions per
-    // k-step, which is what the counted waits below rely on.
+    // ---- issue side: global -> LDS, no registers.  Each wave moves 4 pieces of 1 KiB (16 rows x
+    // 64 B, contiguous in the panel layout) per k-step; the lanes of a piece permute its 16-B chunks
+    // into the swizzled LDS image.  Rows past the end of the table / batch are zero rows of the
+    // padded panels.  Ahead of a tile's first k-step waves 0-2 fetch its epilogue inputs (one DMA
+    // each).  Every wave issues 4 (+1) instructions per k-step, in stream order: that is what the
+    // counted waits below rely on; extra instructions only make them conservative.
+    uint32_t tr_i = 0, tq_i = 0, s_iss = next_tile(xcd, tr_i, tq_i);
+    if (s_iss >= n_sup) return;  // no tile for this block (uniform over the block)
+    uint32_t ks_iss = 0, tile_iss = 0;
+    bool iss_live = true;
     const char* src[kPiecesPerWave];
+    const char* aux_src = nullptr;
+    auto set_src = [&]() {
+        const uint32_t row0 = a.row_lo + tr_i * kTile, q0 = tq_i * kTile;
+        const char* Ab = static_cast<const char*>(a.A) + (size_t)(row0 >> 8) * a.ksteps * kTileBytes;
+        const char* Bb = static_cast<const char*>(a.B) + (size_t)tq_i * a.ksteps * kTileBytes;
 #pragma unroll
-    for (int i = 0; i < kPiecesPerWave; ++i) {
-        const int piece = wave * kPiecesPerWave + i;  // 0..15: A, 16..31: B   (wave-uniform)
-        const bool isA = piece < 16;
-        const int rin = (piece & 15) * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ((rin >> 2) & 3);
-        uint32_t grow = (isA ? row0 : q0) + (uint32_t)rin;
-        const uint32_t last = (isA ? a.row_hi : a.nq) - 1u;
-        grow = grow < last ? grow : last;
-        src[i] = (isA ? Ab : Bb) + (size_t)grow * row_bytes + c * 16;
-    }
-    uint32_t issued = 0;  // k-steps handed to the DMA so far
+        for (int i = 0; i < kPiecesPerWave; ++i) {
+            const int piece = wave * kPiecesPerWave + i;  // 0..15: A, 16..31: B   (wave-uniform)
+            const int rin = (piece & 15) * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((rin >> 2) & 3);
+            src[i] = (piece < 16 ? Ab : Bb) + rin * kRowB + c * 16;
+        }
+        aux_src = wave == 0   ? reinterpret_cast<const char*>(a.nx + row0)
+                  : wave == 1 ? reinterpret_cast<const char*>(a.tauhat + q0)
+                              : reinterpret_cast<const char*>(a.off + q0);
+        aux_src += lane * 16;
+    };
+    set_src();
     auto stage = [&](int slot) {
-        // past the last k-step: re-read the last one (never computed; keeps the DMA count uniform)
-        const int back = issued < a.ksteps ? 0 : kRowB;
+        if (iss_live && ks_iss == 0 && wave < 3) {
+            unsigned char* dst = aux_s + (tile_iss & 3u) * kAuxBytes + wave * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)aux_src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+        const size_t koff = (size_t)ks_iss * kTileBytes;
 #pragma unroll
         for (int i = 0; i < kPiecesPerWave; ++i) {
             const int piece = wave * kPiecesPerWave + i;
             unsigned char* dst = smem + slot * kStageBytes + (piece < 16 ? 0 : kTileBytes) + (piece & 15) * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] - back),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + koff),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            if (back == 0) src[i] += kRowB;
         }
-        issued += 1;
+        if (iss_live && ++ks_iss == a.ksteps) {
+            s_iss = next_tile(s_iss + 8u, tr_i, tq_i);
+            if (s_iss < n_sup) {
+                set_src();
+                ks_iss = 0;
+                tile_iss += 1;
+            } else {  // past the last tile: keep re-reading its last k-step (never computed)
+                iss_live = false;
+                ks_iss = a.ksteps - 1u;
+            }
+        }
     };
 
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
+    // ---- compute side
     const int swz = (li >> 2) & 3;  // (row >> 2) & 3 of every row this lane reads (rows li, li+32, ...)
     using frag_t = typename std::conditional<BF16, bf16x8, f32x4>::type;
     // fragments of k-block s (bf16: 16 k, f32: 4 k-pairs) of one stage: two blocks per stage.
@@ -272,6 +326,7 @@ __global__ __launch_bounds__(kGemmThreads) void bf_gemm_filter(GemmArgs a) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) bfr[n] = *reinterpret_cast<const frag_t*>(Bt + n * 32 * kRowB);
     };
+    f32x16 acc[4][2];
     auto mma = [&](const frag_t (&af)[4], const frag_t (&bfr)[2]) {
         if constexpr (BF16) {
 #pragma unroll
@@ -290,64 +345,99 @@ __global__ __launch_bounds__(kGemmThreads) void bf_gemm_filter(GemmArgs a) {
         }
     };
 
-    // Ring protocol.  Iteration ks computes slot ks % 4 while the DMA of steps ks+1 .. ks+3 is in
-    // flight.  A wave's DMA instructions retire in order, so `vmcnt(8)` at the end of iteration ks
-    // means its pieces of step ks+1 have landed (the 8 youngest = steps ks+2, ks+3 may still fly);
+    // Ring protocol.  Stream step g sits in slot g % 4; while it is computed the DMA of steps g+1 ..
+    // g+3 is in flight.  A wave's DMA instructions retire in order, so `vmcnt(8)` at the end of step
+    // g means its pieces of step g+1 have landed (the 8 youngest = steps g+2, g+3 may still fly);
     // the barrier then makes that true for every wave, and also says every wave is done reading
-    // slot ks % 4, which the next iteration refills with step ks+4.  Steps past the end are issued
-    // as re-reads of the last step (cheap, keeps the counts uniform) and never computed.
+    // slot g % 4, which the next iteration refills with step g+4.
+    // Fragment reads run one k-block ahead of the MFMAs that consume them (two register sets), so
+    // the LDS latency hides behind 8 (bf16) / 32 (f32) MFMAs.  The sched_barriers pin that order:
+    // left alone, hipcc sinks the reads next to their use and recycles one register set.
+    const bool is_l2 = a.metric == 0;
     const uint32_t nk = a.ksteps;
     for (int p = 0; p < kStages - 1; ++p) stage(p);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    // Fragment reads run one k-block ahead of the MFMAs that consume them (two register sets), so
-    // the LDS latency hides behind 8 (bf16) / 32 (f32) MFMAs instead of stalling every group of 4.
-    // The sched_barriers pin that order: left alone, hipcc sinks the reads next to their use and
-    // recycles one register set.
     frag_t a0[4], b0[2], a1[4], b1[2];
     load_frags(0, 0, a0, b0);
-    for (uint32_t ks = 0; ks < nk; ++ks) {
-        const int slot = (int)(ks & (kStages - 1));
-        stage((int)((ks + kStages - 1) & (kStages - 1)));
-        load_frags(slot, 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // slot + 1 always holds landed data (past the end: the re-read of the last step)
-        load_frags((slot + 1) & (kStages - 1), 0, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the over-issued steps before LDS is released
+    uint32_t g = 0, tile_cmp = 0, tr = 0, tq = 0;
+    for (uint32_t s_cmp = next_tile(xcd, tr, tq); s_cmp < n_sup; s_cmp = next_tile(s_cmp + 8u, tr, tq), ++tile_cmp) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    // epilogue: column = query (lane & 31), registers = base rows.  approx dist = (nx - 2 dot) + off;
-    // pairs at or below the query's running threshold are appended to its candidate buffer.
-    const bool is_l2 = a.metric == 0;
+        for (uint32_t ks = 0; ks < nk; ++ks, ++g) {
+            const int slot = (int)(g & (kStages - 1));
+            stage((int)((g + kStages - 1) & (kStages - 1)));
+            load_frags(slot, 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // slot + 1 holds landed data: the next k-step, the next tile's first, or the re-read
+            load_frags((slot + 1) & (kStages - 1), 0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            // the reads of a0/b0 are 8+ MFMAs old here: retire them now, so that the next
+            // iteration's first MFMA does not wait for the a1/b1 reads issued just before it
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(b0[0]), "+v"(b0[1]));
+        }
+
+        // Epilogue: column = query (lane & 31), registers = base rows.  approx dist = (nx - 2 dot) +
+        // off; pairs at or below the query's running threshold are appended to its candidate buffer.
+        // Almost nothing passes (k' of every slab's rows per query), so 16 outputs at a time are
+        // screened by their minimum against a threshold moved to the dot's side of the sum (with
+        // slack for the rounding of that move); only a screened group runs the exact test.
+        const unsigned char* aux = aux_s + (tile_cmp & 3u) * kAuxBytes;
+        const float* nx_s = reinterpret_cast<const float*>(aux);
+        const uint32_t* th_s = reinterpret_cast<const uint32_t*>(aux + 1024);
+        const float* off_s = reinterpret_cast<const float*>(aux + 2048);
+        const uint32_t row0 = a.row_lo + tr * kTile, q0 = tq * kTile;
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const uint32_t q = q0 + wc * 64 + n * 32 + li;
-        const bool qok = q < a.nq;
-        const float tauf = qok ? ord2f(a.tauhat[q]) : -__builtin_inff();   // all-ones decodes to NaN: handled below
-        const bool open = qok && a.tauhat[q] == 0xFFFFFFFFu;               // no threshold yet: everything passes
-        const float offq = qok ? a.off[q] : 0.f;
+        for (int n = 0; n < 2; ++n) {
+            const int qi = wc * 64 + n * 32 + li;
+            const uint32_t q = q0 + qi;
+            const bool qok = q < a.nq;
+            const uint32_t th = th_s[qi];
+            const bool open = th == 0xFFFFFFFFu;  // no threshold yet: everything passes
+            const float tauf = ord2f(th), offq = off_s[qi];
+            float screen = (tauf - offq) + 1e-6f * (__builtin_fabsf(tauf) + __builtin_fabsf(offq));
+            screen = !qok ? -__builtin_inff() : open ? __builtin_inff() : screen;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < 4; ++m) {
+                float sc[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rin = wr * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const uint32_t row = row0 + rin;
-                const float dot = acc[m][n][r];
-                const float dh = (is_l2 ? nx_s[rin] - 2.0f * dot : -dot) + offq;
-                if (qok && row < a.row_hi && (open || dh <= tauf)) {
-                    const uint32_t pos = atomicAdd(&a.count[q], 1u);
-                    if (pos < a.cap) a.entries[(size_t)q * a.cap + pos] = ((uint64_t)f2ord(dh) << 32) | row;
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 nv = *reinterpret_cast<const f32x4*>(nx_s + wr * 128 + m * 32 + 8 * j + 4 * h);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float dot = acc[m][n][4 * j + i];
+                        sc[4 * j + i] = is_l2 ? nv[i] - 2.0f * dot : -dot;
+                    }
+                }
+                float mn = sc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mn = __builtin_fminf(mn, sc[r]);
+                if (__builtin_amdgcn_ballot_w64(mn <= screen) == 0) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t row = row0 + wr * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float dh = sc[r] + offq;
+                    if (qok && row < a.row_hi && (open || dh <= tauf)) {
+                        const uint32_t pos = atomicAdd(&a.count[q], 1u);
+                        if (pos < a.cap) a.entries[(size_t)q * a.cap + pos] = ((uint64_t)f2ord(dh) << 32) | row;
+                    }
                 }
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the over-issued steps before LDS is released
 }
 
 // ------------------------------------------------------------------ exact re-rank
@@ -435,7 +525,7 @@ int launch_bf_prepare(const float* d_raw, uint32_t n, uint32_t dim, uint32_t vst
     hipLaunchKernelGGL(bf_colsum_partial, dim3(kSumBlocks), dim3(256), 0, stream, d_raw, n, vstride, partial);
     hipLaunchKernelGGL(bf_colsum_final, dim3(1), dim3(256), 0, stream, partial, n, vstride, d_mu, d_stats);
     if (n)
-        hipLaunchKernelGGL(bf_center, dim3((n + 3) / 4), dim3(256), 0, stream, d_raw, n, dim, vstride, kp64, d_mu, d_xc,
+        hipLaunchKernelGGL(bf_center, dim3((((n + 255u) & ~255u) + 3) / 4), dim3(256), 0, stream, d_raw, n, dim, vstride, kp64, d_mu, d_xc,
                            static_cast<__bf16*>(d_xb), d_nx, d_stats);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -455,12 +545,14 @@ size_t bf_mfma_workspace_bytes(uint32_t nq, uint32_t vstride, uint32_t kp64) {
     size_t b = 0;
     auto add = [&](size_t bytes) { b += (bytes + 255) / 256 * 256; };
     add((size_t)nq * 4);                  // count
-    add((size_t)nq * 4);                  // tauhat
+    add(((size_t)nq + 255) / 256 * 256 * 4);  // tauhat (whole 256-query tiles are fetched)
     add((size_t)nq * 4);                  // overflow
     add((size_t)nq * kBfMfmaCap * 8);     // entries
-    add((size_t)nq * vstride * 4);        // qf
-    add((size_t)nq * kp64 * 2);           // qb
-    add((size_t)nq * 4 * 3);              // off, eps, cert
+    const size_t nqpad = ((size_t)nq + 255) / 256 * 256;
+    add(nqpad * vstride * 4);             // qf (panels)
+    add(nqpad * kp64 * 2);                // qb (panels)
+    add(((size_t)nq + 255) / 256 * 256 * 4);  // off (same)
+    add((size_t)nq * 4 * 2);              // eps, cert
     add(((size_t)nq + 1) * 4);            // redo
     return b + 4096 + bf_exact_workspace_bytes(nq);
 }
@@ -474,20 +566,21 @@ int launch_bf_mfma(const BfDeviceData& d, int precision, const float* d_queries,
     const uint32_t kprime = bf_mfma_kprime(k, precision);
 
     char* p = static_cast<char*>(workspace);
+    const size_t nqpad = ((size_t)nq + 255) / 256 * 256;  // the GEMM fetches whole 256-query tiles
     uint32_t* count = carve<uint32_t>(p, nq);
-    uint32_t* tauhat = carve<uint32_t>(p, nq);
+    uint32_t* tauhat = carve<uint32_t>(p, nqpad);
     uint32_t* overflow = carve<uint32_t>(p, nq);
     uint64_t* entries = carve<uint64_t>(p, (size_t)nq * kBfMfmaCap);
-    float* qf = carve<float>(p, (size_t)nq * d.vstride);
-    __bf16* qb = carve<__bf16>(p, (size_t)nq * d.kp64);
-    float* off = carve<float>(p, nq);
+    float* qf = carve<float>(p, nqpad * d.vstride);
+    __bf16* qb = carve<__bf16>(p, nqpad * d.kp64);
+    float* off = carve<float>(p, nqpad);
     float* eps = carve<float>(p, nq);
     float* cert = carve<float>(p, nq);
     uint32_t* redo = carve<uint32_t>(p, (size_t)nq + 1);
     void* exact_ws = p;
 
     hipError_t e = hipMemsetAsync(count, 0, (size_t)nq * 4, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(tauhat, 0xFF, (size_t)nq * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(tauhat, 0xFF, nqpad * 4, stream);
     if (e == hipSuccess) e = hipMemsetAsync(overflow, 0, (size_t)nq * 4, stream);
     if (e == hipSuccess) e = hipMemsetAsync(redo, 0, 4, stream);
     if (e != hipSuccess) {
@@ -496,12 +589,11 @@ int launch_bf_mfma(const BfDeviceData& d, int precision, const float* d_queries,
     }
 
     QPrepArgs qa{d_queries, nq, d.dim, d.vstride, d.kp64, d.metric, d.mu, d.stats, qf, qb, off, eps};
-    hipLaunchKernelGGL(bf_prep_queries, dim3((nq + 3) / 4), dim3(256), 0, stream, qa);
+    hipLaunchKernelGGL(bf_prep_queries, dim3((uint32_t)((nqpad + 3) / 4)), dim3(256), 0, stream, qa);
 
     GemmArgs g{};
     g.A = bf16 ? static_cast<const void*>(d.xb) : static_cast<const void*>(d.xc);
     g.B = bf16 ? static_cast<const void*>(qb) : static_cast<const void*>(qf);
-    g.ld = bf16 ? d.kp64 : d.vstride;
     g.ksteps = bf16 ? d.kp64 / 32 : d.vstride / 16;  // 64 B of every row per k-step
     g.nx = d.nx;
     g.off = off;
@@ -534,9 +626,7 @@ int launch_bf_mfma(const BfDeviceData& d, int precision, const float* d_queries,
         g.row_hi = hi;
         g.tiles_r = (hi - lo + kTile - 1) / kTile;
         g.tiles_q = (nq + kTile - 1) / kTile;
-        // super-tiles of 4 x 8 tiles, dealt to the 8 XCDs in turn (see the kernel's block -> tile map)
-        const uint32_t n_sup = ((g.tiles_r + 3) / 4) * ((g.tiles_q + 7) / 8);
-        const dim3 grid(((n_sup + 7) / 8) * 8 * 32);
+        const dim3 grid(kGemmBlocks);  // persistent: the blocks walk the tiles (see the kernel)
         if (bf16) hipLaunchKernelGGL((bf_gemm_filter<true>), grid, dim3(kGemmThreads), 0, stream, g);
         else hipLaunchKernelGGL((bf_gemm_filter<false>), grid, dim3(kGemmThreads), 0, stream, g);
         e = hipGetLastError();

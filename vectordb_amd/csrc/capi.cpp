@@ -195,9 +195,11 @@ void upload_bf(vdb_bruteforce* bf, int device) {
     }
     // centred f32 / bf16 copies, norms and the mean for the MFMA candidate pass (bf_mfma.hip)
     const uint32_t kp64 = (uint32_t)round_up(h.dim, 64);
-    bf->xc.alloc(n * (size_t)vstride * 4);
-    bf->xb.alloc(n * (size_t)kp64 * 2);
-    bf->nx.alloc(n * 4);
+    const size_t npad = round_up(n, 256);  // the GEMM operands are stored in 256-row panels (bf_mfma.hip)
+    bf->xc.alloc(npad * (size_t)vstride * 4);
+    bf->xb.alloc(npad * (size_t)kp64 * 2);
+    bf->nx.alloc(npad * 4);
+    if (npad) VDB_HIP(hipMemset(bf->nx.p, 0, npad * 4));
     bf->mu.alloc((size_t)kp64 * 4);
     bf->stats.alloc(16);
     {
