@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kGemmThreads) void bf_gemm_filter(GemmArgs a) {
     // beside an LDS-DMA target makes hipcc drain the DMA before every LDS read)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kStages * kStageBytes + 4 * kAuxBytes];
     unsigned char* aux_s = smem + kStages * kStageBytes;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar
     const int wr = wave >> 2, wc = wave & 3, h = lane >> 5, li = lane & 31;
     const uint32_t xcd = blockIdx.x & 7u, in = blockIdx.x >> 3;
     const uint32_t sup_q = (a.tiles_q + 7u) >> 3, n_sup = sup_q * ((a.tiles_r + 3u) >> 2);
@@ -285,20 +285,21 @@ __global__ __launch_bounds__(kGemmThreads) void bf_gemm_filter(GemmArgs a) {
         aux_src += lane * 16;
     };
     set_src();
-    auto stage = [&](int slot) {
-        if (iss_live && ks_iss == 0 && wave < 3) {
+    // one k-step = stage_begin, 4 x stage_piece, stage_end (the pieces are spread between MFMAs)
+    size_t koff = 0;
+    auto stage_begin = [&]() { koff = (size_t)ks_iss * kTileBytes; };
+    auto stage_piece = [&](int slot, int i) {
+        if (i == 0 && iss_live && ks_iss == 0 && wave < 3) {
             unsigned char* dst = aux_s + (tile_iss & 3u) * kAuxBytes + wave * 1024;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)aux_src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
-        const size_t koff = (size_t)ks_iss * kTileBytes;
-#pragma unroll
-        for (int i = 0; i < kPiecesPerWave; ++i) {
-            const int piece = wave * kPiecesPerWave + i;
-            unsigned char* dst = smem + slot * kStageBytes + (piece < 16 ? 0 : kTileBytes) + (piece & 15) * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + koff),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
+        const int piece = wave * kPiecesPerWave + i;
+        unsigned char* dst = smem + slot * kStageBytes + (piece < 16 ? 0 : kTileBytes) + (piece & 15) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + koff),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    auto stage_end = [&]() {
         if (iss_live && ++ks_iss == a.ksteps) {
             s_iss = next_tile(s_iss + 8u, tr_i, tq_i);
             if (s_iss < n_sup) {
@@ -311,39 +312,52 @@ __global__ __launch_bounds__(kGemmThreads) void bf_gemm_filter(GemmArgs a) {
             }
         }
     };
+    auto stage = [&](int slot) {
+        stage_begin();
+#pragma unroll
+        for (int i = 0; i < kPiecesPerWave; ++i) stage_piece(slot, i);
+        stage_end();
+    };
 
     // ---- compute side
     const int swz = (li >> 2) & 3;  // (row >> 2) & 3 of every row this lane reads (rows li, li+32, ...)
     using frag_t = typename std::conditional<BF16, bf16x8, f32x4>::type;
     // fragments of k-block s (bf16: 16 k, f32: 4 k-pairs) of one stage: two blocks per stage.
     // bf16: lane half h owns k = 16 s + 8 h .. +7; f32: k = 8 h + 4 s .. +3 (A and B alike).
+    auto frag_pos = [&](int s) { return (((BF16 ? 2 * s + h : 2 * h + s)) ^ swz) * 16; };
+    auto read_a = [&](int slot, int s, int m) {
+        return *reinterpret_cast<const frag_t*>(smem + slot * kStageBytes + (wr * 128 + m * 32 + li) * kRowB + frag_pos(s));
+    };
+    auto read_b = [&](int slot, int s, int n) {
+        return *reinterpret_cast<const frag_t*>(smem + slot * kStageBytes + kTileBytes + (wc * 64 + n * 32 + li) * kRowB +
+                                                frag_pos(s));
+    };
     auto load_frags = [&](int slot, int s, frag_t (&af)[4], frag_t (&bfr)[2]) {
-        const int pos = (((BF16 ? 2 * s + h : 2 * h + s)) ^ swz) * 16;
-        const unsigned char* At = smem + slot * kStageBytes + (wr * 128 + li) * kRowB + pos;
-        const unsigned char* Bt = smem + slot * kStageBytes + kTileBytes + (wc * 64 + li) * kRowB + pos;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const frag_t*>(At + m * 32 * kRowB);
+        for (int m = 0; m < 4; ++m) af[m] = read_a(slot, s, m);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) bfr[n] = *reinterpret_cast<const frag_t*>(Bt + n * 32 * kRowB);
+        for (int n = 0; n < 2; ++n) bfr[n] = read_b(slot, s, n);
     };
     f32x16 acc[4][2];
-    auto mma = [&](const frag_t (&af)[4], const frag_t (&bfr)[2]) {
+    // the MFMAs of output rows m*32 .. +31 of this wave (both query halves): 2 (bf16) or 8 (f32)
+    auto mma_m = [&](auto M, const frag_t (&af)[4], const frag_t (&bfr)[2]) {
+        constexpr int m = decltype(M)::value;
         if constexpr (BF16) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < 2; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
         } else {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][c], bfr[n][c], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][c], bfr[n][c], acc[m][n], 0, 0, 0);
         }
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
 
     // Ring protocol.  Stream step g sits in slot g % 4; while it is computed the DMA of steps g+1 ..
     // g+3 is in flight.  A wave's DMA instructions retire in order, so `vmcnt(8)` at the end of step
@@ -354,12 +368,16 @@ __global__ __launch_bounds__(kGemmThreads) void bf_gemm_filter(GemmArgs a) {
     // the LDS latency hides behind 8 (bf16) / 32 (f32) MFMAs.  The sched_barriers pin that order:
     // left alone, hipcc sinks the reads next to their use and recycles one register set.
     const bool is_l2 = a.metric == 0;
+    const bool early = wr == 0;
     const uint32_t nk = a.ksteps;
     for (int p = 0; p < kStages - 1; ++p) stage(p);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     frag_t a0[4], b0[2], a1[4], b1[2];
     load_frags(0, 0, a0, b0);
+    // (retired here as at the end of every iteration: with reads pending on any path into the
+    // loop hipcc waits for ALL LDS reads, the fresh a1/b1 ones included, ahead of the first MFMA)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(b0[0]), "+v"(b0[1]));
     uint32_t g = 0, tile_cmp = 0, tr = 0, tq = 0;
     for (uint32_t s_cmp = next_tile(xcd, tr, tq); s_cmp < n_sup; s_cmp = next_tile(s_cmp + 8u, tr, tq), ++tile_cmp) {
 #pragma unroll
@@ -370,20 +388,72 @@ __global__ __launch_bounds__(kGemmThreads) void bf_gemm_filter(GemmArgs a) {
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
         for (uint32_t ks = 0; ks < nk; ++ks, ++g) {
-            const int slot = (int)(g & (kStages - 1));
-            stage((int)((g + kStages - 1) & (kStages - 1)));
-            load_frags(slot, 1, a1, b1);
+            const int slot = (int)(g & (kStages - 1)), nslot = (int)((g + 1) & (kStages - 1));
+            const int fill = (int)((g + kStages - 1) & (kStages - 1));  // step g+3 goes where g-1 was
+            stage_begin();
+            // first half: MFMAs of k-block 0 (a0, b0); reads of k-block 1; the early issuers' DMA
+            if (early) stage_piece(fill, 0);
+            a1[0] = read_a(slot, 1, 0);
+            a1[1] = read_a(slot, 1, 1);
             __builtin_amdgcn_sched_barrier(0);
-            mma(a0, b0);
+            mma_m(I0{}, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            if (early) stage_piece(fill, 1);
+            a1[2] = read_a(slot, 1, 2);
+            a1[3] = read_a(slot, 1, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_m(I1{}, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (early) stage_piece(fill, 2);
+            b1[0] = read_b(slot, 1, 0);
+            b1[1] = read_b(slot, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_m(I2{}, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (early) stage_piece(fill, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_m(I3{}, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            // step g+1 landed: behind it the early issuers have 8 younger instructions, the late 4.
+            // (a1/b1 named as operands: hipcc then knows they are complete and puts no wait of its
+            // own, which would cover the fresh a0/b0 reads as well, ahead of the MFMAs below)
+            if (early)
+                asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)"
+                             : "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]), "+v"(b1[0]), "+v"(b1[1])
+                             :
+                             : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)"
+                             : "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]), "+v"(b1[0]), "+v"(b1[1])
+                             :
+                             : "memory");
             __builtin_amdgcn_s_barrier();
-            // slot + 1 holds landed data: the next k-step, the next tile's first, or the re-read
-            load_frags((slot + 1) & (kStages - 1), 0, a0, b0);
+            // second half: MFMAs of k-block 1 (a1, b1); reads of the next step's k-block 0 (slot + 1
+            // holds landed data: the next k-step, the next tile's first, or the re-read); late DMA
+            if (!early) stage_piece(fill, 0);
+            a0[0] = read_a(nslot, 0, 0);
+            a0[1] = read_a(nslot, 0, 1);
             __builtin_amdgcn_sched_barrier(0);
-            mma(a1, b1);
+            mma_m(I0{}, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
-            // the reads of a0/b0 are 8+ MFMAs old here: retire them now, so that the next
+            if (!early) stage_piece(fill, 1);
+            a0[2] = read_a(nslot, 0, 2);
+            a0[3] = read_a(nslot, 0, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_m(I1{}, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!early) stage_piece(fill, 2);
+            b0[0] = read_b(nslot, 0, 0);
+            b0[1] = read_b(nslot, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_m(I2{}, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!early) stage_piece(fill, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_m(I3{}, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_end();
+            // the reads of a0/b0 are several MFMAs old here: retire them now, so that the next
             // iteration's first MFMA does not wait for the a1/b1 reads issued just before it
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(b0[0]), "+v"(b0[1]));
