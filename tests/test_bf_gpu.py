@@ -132,6 +132,24 @@ def test_mfma_fp32_path_is_exact(orc, n, dim, metric, k):
     np.testing.assert_array_equal(d.view(np.uint32), r["dist"].view(np.uint32))
 
 
+@pytest.mark.parametrize("n,nq,dim,metric", [(9100, 2500, 64, vi.L2), (16500, 700, 24, vi.IP)])
+def test_mfma_many_query_tiles(orc, n, nq, dim, metric):
+    """More than one 8-tile super-tile of queries, ragged in both directions (the persistent GEMM's
+    tile walk, the padded panels and the DMA-staged thresholds all see partial tiles)."""
+    x = datasets.clustered(n, dim, 51, normalize=(metric == vi.IP))
+    q = datasets.clustered(nq, dim, 52, normalize=(metric == vi.IP))
+    space = vi.L2Space(dim) if metric == vi.L2 else vi.InnerProductSpace(dim)
+    b = vi.BruteforceSearch(space, n)
+    b.add_items(x)
+    b.to_device(0)
+    d, l = b.search_batch(q, 10, precision=vi.BF_FP32)
+    r = oracle_bf(orc, x, None, metric, q, 10)
+    np.testing.assert_array_equal(l, r["label"].astype(np.uint64))
+    np.testing.assert_array_equal(d.view(np.uint32), r["dist"].view(np.uint32))
+    d2, l2 = b.search_batch(q, 10, precision=vi.BF_BF16_RERANK)
+    assert datasets.recall_at_k(l2, l) >= 0.99
+
+
 def test_mfma_fp32_ties_fall_back_to_exact(orc):
     """Duplicated rows: the k-th exact distance equals distances the candidate pass dropped, the
     certificate cannot hold, and the exact scan re-runs those queries."""
