@@ -124,12 +124,31 @@ size_t vdb_index_device_bytes(const vdb_index* idx);
  *                         (the reference's metric_distance_computations_/metric_hops_,
  *                          hnsw_core.hpp:95-96, :1122-1123, per query)
  *   stream     hipStream_t (NULL = default stream); the call is asynchronous.
- * Filters and deleted elements (the non-bare path, :1141-1148) -> VDB_ERR_UNSUPPORTED. */
+ * Elements marked deleted before the upload are skipped as the reference's non-bare path does
+ * (:1141-1148: they are traversed, never returned). */
 int vdb_search_batch_device(const vdb_index* idx, const float* d_queries, size_t nq, size_t k,
                             float* d_out_dist, uint64_t* d_out_label, uint32_t* d_out_stats, void* stream);
 /* Same with HOST pointers (copies in and out, synchronises; PCIe-inclusive). */
 int vdb_search_batch(const vdb_index* idx, const float* queries, size_t nq, size_t k, float* out_dist,
                      uint64_t* out_label, uint32_t* out_stats);
+
+/* searchKnn(query, k, filter): the non-bare searchBaseLayerST of hnsw_core.hpp:1141-1148 with a
+ * BaseFilterFunctor (hnswlib.hpp:10-23).  A functor cannot cross the ABI; its verdicts can:
+ *   d_allow  DEVICE bitmap over INTERNAL ids, ceil(count / 32) u32 words, bit (i % 32) of word
+ *            i / 32 set = filter(label of element i) is true.  vdb_index_labels() gives the labels
+ *            in internal-id order to evaluate the functor on.  NULL = no filter.
+ * Deleted elements are excluded as well.  Nodes that are not allowed are still traversed (:340-343).
+ * A query whose live candidates outside the result set outnumber what the kernel keeps (256-1024
+ * keys by ef; a filter that rejects almost everything - use brute force there) is not answered
+ * approximately: its output row is NaN / UINT64_MAX and stats.found = UINT32_MAX; the host-pointer
+ * variant then returns VDB_ERR_UNSUPPORTED (the other rows are valid). */
+int vdb_search_batch_device_filtered(const vdb_index* idx, const float* d_queries, size_t nq, size_t k,
+                                     const uint32_t* d_allow, float* d_out_dist, uint64_t* d_out_label,
+                                     uint32_t* d_out_stats, void* stream);
+int vdb_search_batch_filtered(const vdb_index* idx, const float* queries, size_t nq, size_t k, const uint32_t* allow,
+                              float* out_dist, uint64_t* out_label, uint32_t* out_stats);
+/* getExternalLabel (hnsw_core.hpp:219-221) for internal ids 0 .. count-1; cap >= count. */
+int vdb_index_labels(const vdb_index* idx, uint64_t* out, size_t cap);
 
 /* ---- BruteforceSearch<float> ------------------------------------------------------ */
 

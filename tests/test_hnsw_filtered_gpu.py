@@ -1,0 +1,119 @@
+"""The non-bare path of searchKnn (hnsw_core.hpp:1141-1148): deleted elements and filter functors.
+
+GPU == oracle(tree64) bit for bit, counters included.  The oracle's searchBaseLayerST<false> is the
+restatement of SURVEY.md §8a row A5 (candidates always, results only when not deleted and
+filter(label), stop test `cand > lowerBound && size == ef`)."""
+import numpy as np
+import pytest
+
+from vectordb_amd import _lib, datasets
+from vectordb_amd import index as vi
+from tests.helpers import assert_same_results, build_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle as o
+    o.build()
+    return o
+
+
+def _delete_both(h, o, labels):
+    for l in labels:
+        h.markDelete(int(l))
+        o.mark_delete(int(l))
+
+
+@pytest.mark.parametrize("frac,ef,k", [(0.1, 32, 10), (0.5, 64, 10), (0.9, 48, 5), (0.3, 200, 100), (0.02, 10, 10)])
+def test_deleted_elements(orc, frac, ef, k):
+    n, dim = 6000, 32
+    x = datasets.clustered(n, dim, 61)
+    q = datasets.clustered(300, dim, 62)
+    labels = np.arange(n, dtype=np.uint64) * 7 + 3
+    h, o = build_pair(orc, x, labels=labels, n_threads=4)
+    rng = np.random.default_rng(5)
+    dead = labels[rng.permutation(n)[: int(frac * n)]]
+    _delete_both(h, o, dead)
+    assert h.getDeletedCount() == len(dead) == o.deleted
+    h.to_device(0)
+    h.setefSearch(ef)
+    o.set_ef(ef)
+    d, l, st = h.search_batch(q, k, stats=True)
+    r = o.search(q, k)
+    assert_same_results((d, l), r, st)
+    assert not np.isin(l, dead).any()
+
+
+def test_deleted_entry_point(orc):
+    """:302-312: an entry point that is not allowed seeds the candidates only."""
+    n, dim = 3000, 16
+    x = datasets.uniform(n, dim, 63)
+    q = datasets.uniform(100, dim, 64)
+    h, o = build_pair(orc, x, n_threads=2)
+    ep_label = int(h.labels()[h.entry])
+    _delete_both(h, o, [ep_label])
+    h.to_device(0)
+    for ef, k in ((1, 1), (16, 4), (64, 10)):
+        h.setefSearch(ef)
+        o.set_ef(ef)
+        d, l, st = h.search_batch(q, k, stats=True)
+        assert_same_results((d, l), o.search(q, k), st)
+        assert not (l == ep_label).any()
+
+
+@pytest.mark.parametrize("mod,keep,ef", [(2, 0, 40), (5, 3, 64), (16, 7, 40)])
+def test_filter_functor(orc, mod, keep, ef):
+    n, dim = 8000, 48
+    x = datasets.clustered(n, dim, 65, normalize=True)
+    q = datasets.clustered(200, dim, 66, normalize=True)
+    labels = np.random.default_rng(3).permutation(n).astype(np.uint64) + 1000
+    h, o = build_pair(orc, x, metric=vi.IP, labels=labels, n_threads=4)
+    h.to_device(0)
+    h.setefSearch(ef)
+    o.set_ef(ef)
+    d, l, st = h.search_batch(q, 10, stats=True, filter=lambda lab: lab % mod == keep)
+    r = o.search(q, 10, filter_mod=mod, filter_keep=keep)
+    assert_same_results((d, l), r, st)
+    found = l[l != np.uint64(0xFFFFFFFFFFFFFFFF)]
+    assert (found % mod == keep).all()
+    # the reference's one-query spelling with a functor
+    one = h.SearchKNNCloserFirst(q[0], 10, filter=lambda lab: lab % mod == keep)
+    assert [b for _, b in one] == [int(v) for v in l[0] if v != np.uint64(0xFFFFFFFFFFFFFFFF)]
+
+
+def test_filter_and_deleted_on_device_tensors(orc):
+    import torch
+    n, dim = 5000, 24
+    x = datasets.clustered(n, dim, 67)
+    q = datasets.clustered(128, dim, 68)
+    h, o = build_pair(orc, x, n_threads=4)
+    dead = np.arange(0, n, 3, dtype=np.uint64)
+    _delete_both(h, o, dead)
+    h.to_device(0)
+    h.setefSearch(50)
+    o.set_ef(50)
+    bitmap = torch.frombuffer(bytearray(h.filter_bitmap(lambda lab: lab % 4 == 1)), dtype=torch.int32).cuda()
+    dq = torch.from_numpy(q).cuda()
+    d, l, st = h.search_batch(dq, 10, stats=True, filter=bitmap)
+    r = o.search(q, 10, filter_mod=4, filter_keep=1)
+    assert_same_results((d.cpu().numpy(), l.cpu().numpy().view(np.uint64)), r, st.cpu().numpy().view(np.uint32))
+
+
+def test_everything_filtered_out(orc):
+    n, dim = 2000, 16
+    x = datasets.uniform(n, dim, 69)
+    q = datasets.uniform(20, dim, 70)
+    h, o = build_pair(orc, x)
+    h.to_device(0)
+    h.setefSearch(20)
+    o.set_ef(20)
+    try:
+        d, l = h.search_batch(q, 5, filter=np.zeros(n, bool))
+    except vi.VdbError as e:  # every node is a candidate that is never a result: may exceed the kernel's capacity
+        assert e.code == _lib.VDB_ERR_UNSUPPORTED
+        return
+    assert (l == np.uint64(0xFFFFFFFFFFFFFFFF)).all() and np.isinf(d).all()
+    r = o.search(q, 5, filter_mod=1, filter_keep=5)  # label % 1 == 5: never
+    assert (r["count"] == 0).all()

@@ -97,7 +97,7 @@ size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
 // Per-stream scratch of the traversal (work list of re-run queries + visited bitmaps).
 struct SearchScratch {
-    DevBuf redo, bitmaps;
+    DevBuf redo, bitmaps, allow;  // allow: delete flags AND the caller's filter, when both exist
     size_t redo_cap = 0;
     uint32_t bitmap_words = 0;
 };
@@ -111,11 +111,12 @@ struct vdb_index {
     uint64_t device_version = ~0ull;
     DevGraph graph{};
     DevBuf vecs, links0, upper_row, upper_links, labels;
+    DevBuf live;  // bit i = element i is not deleted; allocated only when the upload saw deleted elements
     std::mutex scratch_lock;
     std::map<hipStream_t, std::unique_ptr<SearchScratch>> scratch;
 
     size_t device_bytes() const {
-        return device < 0 ? 0 : vecs.bytes + links0.bytes + upper_row.bytes + upper_links.bytes + labels.bytes;
+        return device < 0 ? 0 : vecs.bytes + links0.bytes + upper_row.bytes + upper_links.bytes + labels.bytes + live.bytes;
     }
     void drop_device() {
         if (device < 0) return;
@@ -128,6 +129,7 @@ struct vdb_index {
             upper_row.release();
             upper_links.release();
             labels.release();
+            live.release();
         } catch (...) {
         }
         device = -1;
@@ -329,6 +331,13 @@ void upload(vdb_index* idx, int device) {
                               hipMemcpyHostToDevice));
     }
     if (n) VDB_HIP(hipMemcpy(idx->upper_row.p, up_row.data(), n * 4, hipMemcpyHostToDevice));
+    if (h.deleted != 0) {  // delete flags (byte +2 of the count word, hnsw_core.hpp:784-787) as a bitmap of LIVE elements
+        std::vector<uint32_t> live((n + 31) / 32, 0u);
+        for (size_t i = 0; i < n; ++i)
+            if (!h.is_deleted((uint32_t)i)) live[i >> 5] |= 1u << (i & 31);
+        idx->live.alloc(live.size() * 4);
+        VDB_HIP(hipMemcpy(idx->live.p, live.data(), live.size() * 4, hipMemcpyHostToDevice));
+    }
 
     DevGraph& g = idx->graph;
     g.vecs = (const float*)idx->vecs.p;
@@ -355,8 +364,8 @@ SearchScratch& scratch_for(vdb_index* idx, hipStream_t stream, size_t nq) {
     if (s.redo_cap < nq + 1) {
         // a previous call on this stream may still be using the old buffer
         if (s.redo.p) VDB_HIP(hipStreamSynchronize(stream));
-        s.redo.alloc((nq + 1) * 4 * 2);
-        s.redo_cap = (nq + 1) * 2;
+        s.redo.alloc((nq + 2) * 4 * 2);
+        s.redo_cap = (nq + 2) * 2 - 1;
     }
     const uint32_t words = (idx->graph.n + 31u) / 32u;
     if (!s.bitmaps.p || s.bitmap_words < words) {
@@ -372,8 +381,82 @@ void require_search_ready(const vdb_index* idx) {
     if (idx->device < 0) throw DeviceError("index is not on a device: call vdb_index_to_device first");
     if (idx->device_version != idx->host->version)
         throw DeviceError("index changed since vdb_index_to_device: upload it again");
-    if (idx->host->deleted != 0)
-        throw Unsupported("search with deleted elements (non-bare path, hnsw_core.hpp:1141-1148) is not on the device path yet");
+}
+
+// searchKnn over a batch; d_filter = nullable device bitmap over internal ids (1 = passes the filter).
+int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, const uint32_t* d_filter, float* d_out_dist,
+                  uint64_t* d_out_label, uint32_t* d_out_stats, hipStream_t stream, uint32_t** fail_word) {
+    require_search_ready(idx);
+    if (nq == 0) return (int)VDB_OK;
+    if (!d_queries || !d_out_dist || !d_out_label) throw std::invalid_argument("null buffer");
+    if (k == 0) throw std::invalid_argument("k must be > 0");
+    if (nq > 0x7FFFFFFFull || k > 0x7FFFFFFFull) throw std::invalid_argument("batch too large");
+    DeviceGuard guard(idx->device);
+    const size_t ef = std::max(idx->host->ef_search, k);  // hnsw_core.hpp:1144
+    if (ef > kMaxEf) throw Unsupported("max(efSearch, k) above 256 is not supported by the device path");
+    std::unique_lock<std::mutex> lock(idx->scratch_lock);
+    SearchScratch& s = scratch_for(idx, stream, nq);
+    // bare = no deleted element and no filter (hnsw_core.hpp:1141); else one bitmap of allowed nodes
+    const uint32_t* allow = d_filter;
+    const uint32_t words = (idx->graph.n + 31u) / 32u;
+    if (idx->live.p) {
+        allow = (const uint32_t*)idx->live.p;
+        if (d_filter) {
+            if (s.allow.bytes < (size_t)words * 4) {
+                if (s.allow.p) VDB_HIP(hipStreamSynchronize(stream));
+                s.allow.alloc((size_t)std::max(words, 1u) * 4);
+            }
+            if (launch_and_bitmaps((const uint32_t*)idx->live.p, d_filter, (uint32_t*)s.allow.p, words, stream) != 0)
+                throw DeviceError("bitmap kernel launch failed");
+            allow = (const uint32_t*)s.allow.p;
+        }
+    }
+    HnswSearchWork work;
+    work.redo = (uint32_t*)s.redo.p;
+    work.bitmaps = (uint32_t*)s.bitmaps.p;
+    work.bitmap_words = s.bitmap_words;
+    if (fail_word) *fail_word = work.redo + 1;
+    std::string err;
+    const int rc = launch_hnsw_search(idx->graph, d_queries, (uint32_t)nq, (uint32_t)k, (uint32_t)ef, allow, d_out_dist,
+                                      d_out_label, d_out_stats, work, stream, &err);
+    if (rc != 0) return set_error(rc, err);
+    return (int)VDB_OK;
+}
+
+int search_host(vdb_index* idx, const float* queries, size_t nq, size_t k, const uint32_t* filter, float* out_dist,
+                uint64_t* out_label, uint32_t* out_stats) {
+    require_search_ready(idx);
+    if (nq == 0) return (int)VDB_OK;
+    if (!queries || !out_dist || !out_label) throw std::invalid_argument("null buffer");
+    if (k == 0) throw std::invalid_argument("k must be > 0");
+    DeviceGuard guard(idx->device);
+    const size_t dim = idx->host->dim;
+    DevBuf dq, dd, dl, ds, df;
+    dq.alloc(nq * dim * 4);
+    dd.alloc(nq * k * 4);
+    dl.alloc(nq * k * 8);
+    if (out_stats) ds.alloc(nq * 16);
+    VDB_HIP(hipMemcpy(dq.p, queries, nq * dim * 4, hipMemcpyHostToDevice));
+    if (filter) {
+        const size_t words = ((size_t)idx->graph.n + 31) / 32;
+        df.alloc(std::max<size_t>(words, 1) * 4);
+        VDB_HIP(hipMemcpy(df.p, filter, words * 4, hipMemcpyHostToDevice));
+    }
+    uint32_t* fail_word = nullptr;
+    const int rc = search_device(idx, (const float*)dq.p, nq, k, filter ? (const uint32_t*)df.p : nullptr, (float*)dd.p,
+                                 (uint64_t*)dl.p, out_stats ? (uint32_t*)ds.p : nullptr, nullptr, &fail_word);
+    if (rc != VDB_OK) return rc;
+    VDB_HIP(hipStreamSynchronize(nullptr));
+    uint32_t failed = 0;
+    if (fail_word) VDB_HIP(hipMemcpy(&failed, fail_word, 4, hipMemcpyDeviceToHost));
+    VDB_HIP(hipMemcpy(out_dist, dd.p, nq * k * 4, hipMemcpyDeviceToHost));
+    VDB_HIP(hipMemcpy(out_label, dl.p, nq * k * 8, hipMemcpyDeviceToHost));
+    if (out_stats) VDB_HIP(hipMemcpy(out_stats, ds.p, nq * 16, hipMemcpyDeviceToHost));
+    if (failed)
+        throw Unsupported(std::to_string(failed) +
+                          " queries hold more live candidates outside the result set than the device search keeps "
+                          "(a filter that rejects almost every element): their rows are NaN / UINT64_MAX");
+    return (int)VDB_OK;
 }
 
 }  // namespace
@@ -515,52 +598,40 @@ size_t vdb_index_device_bytes(const vdb_index* idx) { return idx ? idx->device_b
 int vdb_search_batch_device(const vdb_index* cidx, const float* d_queries, size_t nq, size_t k, float* d_out_dist,
                             uint64_t* d_out_label, uint32_t* d_out_stats, void* stream_) {
     return guarded([&] {
-        vdb_index* idx = const_cast<vdb_index*>(cidx);
-        require_search_ready(idx);
-        if (nq == 0) return (int)VDB_OK;
-        if (!d_queries || !d_out_dist || !d_out_label) throw std::invalid_argument("null buffer");
-        if (k == 0) throw std::invalid_argument("k must be > 0");
-        if (nq > 0x7FFFFFFFull || k > 0x7FFFFFFFull) throw std::invalid_argument("batch too large");
-        hipStream_t stream = (hipStream_t)stream_;
-        DeviceGuard guard(idx->device);
-        const size_t ef = std::max(idx->host->ef_search, k);  // hnsw_core.hpp:1144
-        if (ef > kMaxEf) throw Unsupported("max(efSearch, k) above 256 is not supported by the device path");
-        std::unique_lock<std::mutex> lock(idx->scratch_lock);
-        SearchScratch& s = scratch_for(idx, stream, nq);
-        HnswSearchWork work;
-        work.redo = (uint32_t*)s.redo.p;
-        work.bitmaps = (uint32_t*)s.bitmaps.p;
-        work.bitmap_words = s.bitmap_words;
-        std::string err;
-        const int rc = launch_hnsw_search(idx->graph, d_queries, (uint32_t)nq, (uint32_t)k, (uint32_t)ef, d_out_dist,
-                                          d_out_label, d_out_stats, work, stream, &err);
-        if (rc != 0) return set_error(rc, err);
-        return (int)VDB_OK;
+        return search_device(const_cast<vdb_index*>(cidx), d_queries, nq, k, nullptr, d_out_dist, d_out_label, d_out_stats,
+                             (hipStream_t)stream_, nullptr);
+    });
+}
+
+int vdb_search_batch_device_filtered(const vdb_index* cidx, const float* d_queries, size_t nq, size_t k,
+                                     const uint32_t* d_allow, float* d_out_dist, uint64_t* d_out_label,
+                                     uint32_t* d_out_stats, void* stream_) {
+    return guarded([&] {
+        return search_device(const_cast<vdb_index*>(cidx), d_queries, nq, k, d_allow, d_out_dist, d_out_label, d_out_stats,
+                             (hipStream_t)stream_, nullptr);
     });
 }
 
 int vdb_search_batch(const vdb_index* idx, const float* queries, size_t nq, size_t k, float* out_dist,
                      uint64_t* out_label, uint32_t* out_stats) {
     return guarded([&] {
-        require_search_ready(idx);
-        if (nq == 0) return (int)VDB_OK;
-        if (!queries || !out_dist || !out_label) throw std::invalid_argument("null buffer");
-        if (k == 0) throw std::invalid_argument("k must be > 0");
-        DeviceGuard guard(idx->device);
-        const size_t dim = idx->host->dim;
-        DevBuf dq, dd, dl, ds;
-        dq.alloc(nq * dim * 4);
-        dd.alloc(nq * k * 4);
-        dl.alloc(nq * k * 8);
-        if (out_stats) ds.alloc(nq * 16);
-        VDB_HIP(hipMemcpy(dq.p, queries, nq * dim * 4, hipMemcpyHostToDevice));
-        const int rc = vdb_search_batch_device(idx, (const float*)dq.p, nq, k, (float*)dd.p, (uint64_t*)dl.p,
-                                               out_stats ? (uint32_t*)ds.p : nullptr, nullptr);
-        if (rc != VDB_OK) return rc;
-        VDB_HIP(hipStreamSynchronize(nullptr));
-        VDB_HIP(hipMemcpy(out_dist, dd.p, nq * k * 4, hipMemcpyDeviceToHost));
-        VDB_HIP(hipMemcpy(out_label, dl.p, nq * k * 8, hipMemcpyDeviceToHost));
-        if (out_stats) VDB_HIP(hipMemcpy(out_stats, ds.p, nq * 16, hipMemcpyDeviceToHost));
+        return search_host(const_cast<vdb_index*>(idx), queries, nq, k, nullptr, out_dist, out_label, out_stats);
+    });
+}
+
+int vdb_search_batch_filtered(const vdb_index* idx, const float* queries, size_t nq, size_t k, const uint32_t* allow,
+                              float* out_dist, uint64_t* out_label, uint32_t* out_stats) {
+    return guarded([&] {
+        return search_host(const_cast<vdb_index*>(idx), queries, nq, k, allow, out_dist, out_label, out_stats);
+    });
+}
+
+int vdb_index_labels(const vdb_index* idx, uint64_t* out, size_t cap) {
+    return guarded([&] {
+        if (!idx || !out) throw std::invalid_argument("null argument");
+        const size_t n = idx->host->count;
+        if (cap < n) throw std::invalid_argument("label buffer smaller than the element count");
+        for (size_t i = 0; i < n; ++i) out[i] = idx->host->label_of((uint32_t)i);
         return (int)VDB_OK;
     });
 }

@@ -63,6 +63,7 @@ constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
 constexpr int kDppHalfMirror = 0x141;  // lane i <- lane 7-i inside each 8
 constexpr int kDppMirror = 0x140;      // lane i <- lane 15-i inside each 16
 constexpr int kDppWaveShr1 = 0x138;    // lane i <- lane i-1 over the whole wave
+constexpr int kDppWaveShl1 = 0x130;    // lane i <- lane i+1 over the whole wave
 
 __device__ __forceinline__ uint32_t readlane(uint32_t v, int lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
@@ -221,7 +222,9 @@ struct BitmapVisited {  // exact for any number of visited nodes; one n-bit map 
 // ------------------------------------------------------------------ sorted key array
 
 // Entry i of the array lives in register i/64 of lane i%64.  EMPTY = all ones.
-template <int R>
+// Low word of a key: id << S | flags.  S = 1: bit 0 = expanded.  S = 2 (filtered search): bit 1 =
+// the node is not allowed into the results (deleted, or rejected by the filter), bit 0 = expanded.
+template <int R, int S>
 struct KeyArray {
     uint32_t hi[R], lo[R];
 
@@ -279,7 +282,7 @@ struct KeyArray {
             const uint64_t open = ballot((lo[r] & 1u) == 0u);
             if (open) {
                 const int p = __builtin_ctzll(open);
-                id = readlane(lo[r], p) >> 1;
+                id = readlane(lo[r], p) >> S;
                 dhi = readlane(hi[r], p);
                 return true;
             }
@@ -293,12 +296,84 @@ struct KeyArray {
             const uint64_t open = ballot((lo[r] & 1u) == 0u);
             if (open) {
                 const int p = __builtin_ctzll(open);
-                id = readlane(lo[r], p) >> 1;
+                id = readlane(lo[r], p) >> S;
                 if (lane == p) lo[r] |= 1u;
                 return true;
             }
         }
         return false;
+    }
+
+    // ---- filtered search (S == 2) only
+    // Entry `p` (wave-uniform) leaves the array; everything behind it moves one place forward.
+    __device__ __forceinline__ void erase(uint32_t p, int lane) {
+        uint32_t dh[R], dl[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            dh[r] = dpp_u32<kDppWaveShl1>(kEmptyWord, hi[r]);
+            dl[r] = dpp_u32<kDppWaveShl1>(kEmptyWord, lo[r]);
+            const uint32_t nh = r + 1 < R ? readlane(hi[r + 1 < R ? r + 1 : r], 0) : kEmptyWord;
+            const uint32_t nl = r + 1 < R ? readlane(lo[r + 1 < R ? r + 1 : r], 0) : kEmptyWord;
+            if (lane == 63) {
+                dh[r] = nh;
+                dl[r] = nl;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if ((uint32_t)(r * 64 + lane) >= p) {
+                hi[r] = dh[r];
+                lo[r] = dl[r];
+            }
+        }
+    }
+    // First key with the expanded bit clear.  An allowed node stays (it is a result) with the bit
+    // set; a node that is not allowed was only ever a candidate and leaves the array.
+    __device__ __forceinline__ bool pop_candidate_filtered(int lane, uint32_t& id) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint64_t open = ballot((lo[r] & 1u) == 0u);
+            if (open) {
+                const int p = __builtin_ctzll(open);
+                const uint32_t w = readlane(lo[r], p);
+                id = w >> S;
+                if (w & 2u) erase((uint32_t)(r * 64 + p), lane);
+                else if (lane == p) lo[r] |= 1u;
+                return true;
+            }
+        }
+        return false;
+    }
+    // The result set is the first ef ALLOWED entries.  Full: (bhi, bpos) = distance and index of the
+    // ef-th of them (lowerBound of hnsw_core.hpp:348-349); else false.
+    __device__ __forceinline__ bool bound_filtered(uint32_t ef, uint32_t& bhi, uint32_t& bpos) const {
+        uint32_t base = 0;
+        bool full = false;
+        bhi = kEmptyWord;
+        bpos = kEmptyWord;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool ok = hi[r] != kEmptyWord && (lo[r] & 2u) == 0u;
+            const uint64_t m = ballot(ok);
+            const uint32_t rank = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const uint64_t hit = ballot(ok && rank == ef - 1u);
+            if (hit) {
+                const int p = __builtin_ctzll(hit);
+                bhi = readlane(hi[r], p);
+                bpos = (uint32_t)(r * 64 + p);
+                full = true;
+            }
+            base += (uint32_t)__builtin_popcountll(m);
+        }
+        return full;
+    }
+    // Behind the bound entry only keys AT the bound's distance can still be expanded (:316).
+    __device__ __forceinline__ void trim_filtered(uint32_t bpos, uint32_t bound_hi, int lane) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t idx = (uint32_t)(r * 64 + lane);
+            if (idx > bpos && hi[r] != bound_hi) hi[r] = lo[r] = kEmptyWord;
+        }
     }
 };
 
@@ -311,13 +386,19 @@ struct SearchArgs {
     float* out_dist;       // [nq][k]
     uint64_t* out_label;   // [nq][k]
     uint32_t* out_stats;   // nullable [nq][4]
-    uint32_t* redo;        // [0] = count, [1 + i] = query ids that must be re-run
+    const uint32_t* allow; // filtered search: bit i of word i/32 = node i may enter the results
+    uint32_t* redo;        // [0] = count, [1] = queries that could not be answered, [2 + i] = query ids to re-run
     uint32_t* bitmaps;     // large configuration: [gridDim.x][bitmap_words]
     uint32_t bitmap_words;
 };
 
-template <int NCH, int GPB, int R, bool LARGE, bool IS_L2>
+// FILT = the non-bare searchBaseLayerST (hnsw_core.hpp:1141-1148 with deleted elements or a filter):
+// every admitted node is a candidate, only allowed ones are results (:340-343), the search stops when
+// the best candidate is beyond the ef-th RESULT (:316).  Restated on the one sorted array: see
+// KeyArray (S == 2) and DESIGN.md "Filtered search".
+template <int NCH, int GPB, int R, bool LARGE, bool IS_L2, bool FILT>
 __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
+    constexpr int S = FILT ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = lane_id();
     const DevGraph& g = a.g;
@@ -334,7 +415,7 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
     const uint32_t n_work = LARGE ? a.redo[0] : a.nq;
 #pragma unroll 1
     for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {
-        const uint32_t qi = LARGE ? a.redo[1 + w] : w;
+        const uint32_t qi = LARGE ? a.redo[2 + w] : w;
         const uint32_t k = a.k, ef = a.ef;
         float* od = a.out_dist + (size_t)qi * k;
         uint64_t* ol = a.out_label + (size_t)qi * k;
@@ -406,13 +487,24 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
         }
 
         // ---- layer 0: searchBaseLayerST<bare> (restated from hnsw_core.hpp:293-356)
-        KeyArray<R> arr;
+        KeyArray<R, S> arr;
         arr.clear();
-        if (lane == 0) {
-            arr.hi[0] = cur_d;
-            arr.lo[0] = cur << 1;
+        auto not_allowed = [&](uint32_t id) { return ((a.allow[id >> 5] >> (id & 31u)) & 1u) ^ 1u; };
+        uint32_t bound;  // lowerBound once the result set is full, else "no bound"
+        if constexpr (FILT) {
+            const uint32_t dis = not_allowed(cur);  // :302-312: an entry point that is not allowed is a candidate only
+            if (lane == 0) {
+                arr.hi[0] = cur_d;
+                arr.lo[0] = (cur << 2) | (dis << 1);
+            }
+            bound = (ef == 1 && dis == 0) ? cur_d : kEmptyWord;
+        } else {
+            if (lane == 0) {
+                arr.hi[0] = cur_d;
+                arr.lo[0] = cur << 1;
+            }
+            bound = ef > 1 ? kEmptyWord : cur_d;  // hi of entry ef-1
         }
-        uint32_t bound = ef > 1 ? kEmptyWord : cur_d;  // hi of entry ef-1
         uint32_t nvis = 1;
         bool overflow = false;
         if (lane == 0) (void)vis.test_and_set(cur);
@@ -423,7 +515,7 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
         uint32_t pfa_id = kNoId, pfb_id = kNoId, pfa_row = kNoId, pfb_row = kNoId;
         uint32_t cand;
 #pragma unroll 1
-        while (arr.pop_candidate(lane, cand)) {
+        while (FILT ? arr.pop_candidate_filtered(lane, cand) : arr.pop_candidate(lane, cand)) {
             hops0 += 1;
             if (nvis + g.l0stride > vis.limit()) {
                 overflow = true;
@@ -455,6 +547,8 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
             for (uint32_t c0 = 0; c0 < m_all; c0 += 32) {
                 const uint32_t m = m_all - c0 < 32u ? m_all - c0 : 32u;
                 const uint32_t ids_part = c0 == 0 ? ids_c : bpermute(ids_c, (lane + 32) & 63);
+                uint32_t dis = 0;  // requested ahead of the row gathers, used after them
+                if constexpr (FILT) dis = (uint32_t)lane < m ? not_allowed(ids_part) : 0u;
                 uint32_t dord = score_nodes<NCH, GPB, IS_L2>(g, q, ids_part, m, lane);
                 if ((uint32_t)lane >= m) dord = kEmptyWord;
                 {
@@ -474,10 +568,21 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
                     if (d < bound) {
                         const uint32_t id = readlane(ids_part, r);
                         uint32_t prev_hi, prev_lo;
-                        arr.insert(d, id << 1, lane, prev_hi, prev_lo);
-                        bound = arr.hi_at(ef - 1);
-                        lost |= lane == 63 && prev_hi != kEmptyWord && prev_hi == bound && (prev_lo & 1u) == 0u;
-                        arr.trim(ef, bound, lane);
+                        if constexpr (FILT) {
+                            arr.insert(d, (id << 2) | (readlane(dis, r) << 1), lane, prev_hi, prev_lo);
+                            uint32_t bhi, bpos;
+                            const bool full = arr.bound_filtered(ef, bhi, bpos);
+                            bound = full ? bhi : kEmptyWord;
+                            // a key that fell off the end is missed unless it was dead: with the set full
+                            // it lay behind the bound entry, where only unexpanded keys AT the bound live
+                            lost |= lane == 63 && prev_hi != kEmptyWord && (!full || (prev_hi == bound && (prev_lo & 1u) == 0u));
+                            if (full) arr.trim_filtered(bpos, bound, lane);
+                        } else {
+                            arr.insert(d, id << 1, lane, prev_hi, prev_lo);
+                            bound = arr.hi_at(ef - 1);
+                            lost |= lane == 63 && prev_hi != kEmptyWord && prev_hi == bound && (prev_lo & 1u) == 0u;
+                            arr.trim(ef, bound, lane);
+                        }
                         pend &= ballot(dord < bound);
                     }
                 }
@@ -490,48 +595,84 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
             if constexpr (!LARGE) {
                 if (lane == 0) {
                     const uint32_t slot = atomicAdd(&a.redo[0], 1u);
-                    a.redo[1 + slot] = qi;
+                    a.redo[2 + slot] = qi;
+                }
+                continue;
+            } else if constexpr (FILT) {
+                // more live candidates that are not results than the largest array holds (a filter
+                // that rejects almost everything): reported, never answered approximately
+                for (uint32_t i = lane; i < k; i += 64) {
+                    od[i] = __builtin_nanf("");
+                    ol[i] = ~0ull;
+                }
+                if (lane == 0) {
+                    atomicAdd(&a.redo[1], 1u);
+                    if (a.out_stats) {
+                        uint32_t* st = a.out_stats + (size_t)qi * 4;
+                        st[kStatNdis] = ndis;
+                        st[kStatHops0] = hops0;
+                        st[kStatHopsUpper] = hops_up;
+                        st[kStatFound] = 0xFFFFFFFFu;
+                    }
                 }
                 continue;
             }
         }
 
         // ---- epilogue, hnsw_core.hpp:1150-1158 + hnswlib.hpp:87-99
-        // results = entries 0..min(size, ef)-1; keep the k smallest, order by (dist, label)
+        // results = entries 0..min(size, ef)-1 (filtered: the first ef allowed entries); keep the k
+        // smallest, order by (dist, label).  pos[r] = place of this lane's entry among the results.
+        // place_of(r, base): this lane's entry of register r among the results (kEmptyWord: not one);
+        // `base` runs over the registers in order
+        auto place_of = [&](int r, uint32_t& base) -> uint32_t {
+            if constexpr (FILT) {
+                const bool ok = arr.hi[r] != kEmptyWord && (arr.lo[r] & 2u) == 0u;
+                const uint64_t m = ballot(ok);
+                const uint32_t p = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                base += (uint32_t)__builtin_popcountll(m);
+                return ok ? p : kEmptyWord;
+            } else {
+                const uint32_t idx = (uint32_t)(r * 64 + lane);
+                const bool ok = idx < ef && !(arr.hi[r] == kEmptyWord && arr.lo[r] == kEmptyWord);
+                base += (uint32_t)__builtin_popcountll(ballot(ok));
+                return ok ? idx : kEmptyWord;
+            }
+        };
         uint32_t size = 0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t idx = (uint32_t)(r * 64 + lane);
-            size += (uint32_t)__builtin_popcountll(ballot(idx < ef && !(arr.hi[r] == kEmptyWord && arr.lo[r] == kEmptyWord)));
-        }
+        for (int r = 0; r < R; ++r) (void)place_of(r, size);
+        if (size > ef) size = ef;
         const uint32_t kout = size < k ? size : k;
         // stage (ord dist, label) in LDS, then every entry finds its rank among ties
         __builtin_amdgcn_wave_barrier();
         uint32_t* s_hi = lds;                                        // [64 R]
         uint64_t* s_lab = reinterpret_cast<uint64_t*>(lds + 64 * R);  // [64 R]
         bool tie = false;
+        uint32_t base = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const uint32_t idx = (uint32_t)(r * 64 + lane);
-            uint64_t lab = 0;
-            if (idx < kout) lab = g.labels[arr.lo[r] >> 1];
-            s_hi[idx] = arr.hi[r];
-            s_lab[idx] = lab;
+            const uint32_t pl = place_of(r, base);
+            if (pl < kout) {
+                s_hi[pl] = arr.hi[r];
+                s_lab[pl] = g.labels[arr.lo[r] >> S];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        base = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const uint32_t idx = (uint32_t)(r * 64 + lane);
-            if (idx > 0 && idx < kout && s_hi[idx - 1] == arr.hi[r]) tie = true;
+            const uint32_t pl = place_of(r, base);
+            if (pl > 0 && pl < kout && s_hi[pl - 1] == arr.hi[r]) tie = true;
         }
         const bool any_tie = ballot(tie) != 0ull;
+        base = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const uint32_t idx = (uint32_t)(r * 64 + lane);
-            if (idx < kout) {
-                uint32_t pos = idx;
-                const uint64_t lab = s_lab[idx];
+            const uint32_t pl = place_of(r, base);
+            if (pl < kout) {
+                uint32_t pos = pl;
+                const uint64_t lab = s_lab[pl];
                 if (any_tie) {
                     pos = 0;
                     for (uint32_t j = 0; j < kout; ++j) {
@@ -560,26 +701,31 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void and_bitmaps_kernel(const uint32_t* a, const uint32_t* b, uint32_t* out, uint32_t words) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < words) out[i] = a[i] & b[i];
+}
+
 // ------------------------------------------------------------------ launch
 
-template <int NCH, int GPB, int R>
+template <int NCH, int GPB, int R, int RL, bool FILT>
 int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
     const size_t epilogue_bytes = (size_t)64 * R * 12;
     size_t lds_small = (size_t)4 << a.hbits;
     if (lds_small < epilogue_bytes) lds_small = epilogue_bytes;
     if (a.g.metric == 0)
-        hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, false, true>), dim3(a.nq), dim3(64), lds_small, stream, a);
+        hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, false, true, FILT>), dim3(a.nq), dim3(64), lds_small, stream, a);
     else
-        hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, false, false>), dim3(a.nq), dim3(64), lds_small, stream, a);
+        hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, false, false, FILT>), dim3(a.nq), dim3(64), lds_small, stream, a);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) {
         const uint32_t blocks = a.nq < kLargeBlocks ? a.nq : kLargeBlocks;
         if (a.g.metric == 0)
-            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, 2 * R, true, true>), dim3(blocks), dim3(64),
-                               (size_t)64 * 2 * R * 12, stream, a);
+            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, RL, true, true, FILT>), dim3(blocks), dim3(64),
+                               (size_t)64 * RL * 12, stream, a);
         else
-            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, 2 * R, true, false>), dim3(blocks), dim3(64),
-                               (size_t)64 * 2 * R * 12, stream, a);
+            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, RL, true, false, FILT>), dim3(blocks), dim3(64),
+                               (size_t)64 * RL * 12, stream, a);
         e = hipGetLastError();
     }
     if (e != hipSuccess) {
@@ -591,16 +737,30 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
 
 template <int NCH, int GPB>
 int launch_r(const SearchArgs& a, hipStream_t stream, std::string* err) {
-    if (a.ef <= 64) return launch_cfg<NCH, GPB, 1>(a, stream, err);
-    if (a.ef <= 128) return launch_cfg<NCH, GPB, 2>(a, stream, err);
-    return launch_cfg<NCH, GPB, 4>(a, stream, err);
+    if (a.allow) {
+        // filtered: the array also holds the live candidates that are not results (about
+        // ef / selectivity keys in all) - twice the registers of the bare search, and 1024 keys in
+        // the large configuration
+        if (a.ef <= 64) return launch_cfg<NCH, GPB, 2, 16, true>(a, stream, err);
+        if (a.ef <= 128) return launch_cfg<NCH, GPB, 4, 16, true>(a, stream, err);
+        return launch_cfg<NCH, GPB, 8, 16, true>(a, stream, err);
+    }
+    if (a.ef <= 64) return launch_cfg<NCH, GPB, 1, 2, false>(a, stream, err);
+    if (a.ef <= 128) return launch_cfg<NCH, GPB, 2, 4, false>(a, stream, err);
+    return launch_cfg<NCH, GPB, 4, 8, false>(a, stream, err);
 }
 
 }  // namespace
 
+int launch_and_bitmaps(const uint32_t* a, const uint32_t* b, uint32_t* out, uint32_t words, hipStream_t stream) {
+    if (words == 0) return 0;
+    hipLaunchKernelGGL(and_bitmaps_kernel, dim3((words + 255) / 256), dim3(256), 0, stream, a, b, out, words);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
 int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, uint32_t k, uint32_t ef,
-                       float* d_out_dist, uint64_t* d_out_label, uint32_t* d_out_stats, const HnswSearchWork& work,
-                       hipStream_t stream, std::string* err) {
+                       const uint32_t* d_allow, float* d_out_dist, uint64_t* d_out_label, uint32_t* d_out_stats,
+                       const HnswSearchWork& work, hipStream_t stream, std::string* err) {
     if (nq == 0) return 0;
     auto unsupported = [&](const char* what) {
         if (err) *err = what;
@@ -609,6 +769,7 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
     if (ef == 0 || ef > kMaxEf) return unsupported("ef (= max(efSearch, k)) above 256 is not supported by the device path");
     if (g.vstride > kMaxVecStride) return unsupported("dim above 1024 is not supported by the device path");
     if (g.l0stride > kMaxL0Stride || g.ustride > kMaxL0Stride) return unsupported("M above 32 is not supported by the device path");
+    if (d_allow && g.n >= (1u << 30)) return unsupported("filtered search needs fewer than 2^30 elements per index (shard it)");
     if (!work.redo || (g.n && (!work.bitmaps || work.bitmap_words < (g.n + 31u) / 32u))) {
         if (err) *err = "hnsw_search: workspace missing";
         return 1;
@@ -622,13 +783,14 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
     uint32_t need = (uint32_t)(((uint64_t)ef * g.l0stride * 4u + 2u) / 3u), hb = 10;
     while ((1u << hb) < need && hb < 14) ++hb;
     a.hbits = hb;
+    a.allow = d_allow;
     a.out_dist = d_out_dist;
     a.out_label = d_out_label;
     a.out_stats = d_out_stats;
     a.redo = work.redo;
     a.bitmaps = work.bitmaps;
     a.bitmap_words = work.bitmap_words;
-    hipError_t e = hipMemsetAsync(work.redo, 0, sizeof(uint32_t), stream);
+    hipError_t e = hipMemsetAsync(work.redo, 0, 2 * sizeof(uint32_t), stream);
     if (e != hipSuccess) {
         if (err) *err = std::string("hipMemsetAsync: ") + hipGetErrorString(e);
         return 3;

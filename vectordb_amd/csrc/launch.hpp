@@ -16,7 +16,7 @@ constexpr uint32_t kMaxL0Stride = 64;      // layer-0 list slots (maxM0 <= 64, i
 constexpr uint32_t kLargeBlocks = 128;     // resident waves of the large configuration (one bitmap each)
 
 struct HnswSearchWork {
-    uint32_t* redo = nullptr;     // [1 + nq] u32; [0] is zeroed by the launcher
+    uint32_t* redo = nullptr;     // [2 + nq] u32; [0] (re-run count) and [1] (unanswerable filtered queries) zeroed by the launcher
     uint32_t* bitmaps = nullptr;  // [kLargeBlocks][bitmap_words]
     uint32_t bitmap_words = 0;
 };
@@ -24,9 +24,13 @@ struct HnswSearchWork {
 // Enqueues the search of nq queries on `stream` (two launches: fast configuration, then the
 // large configuration over the queries the first one gave up on).  Returns 0, or a
 // vdb_status with `err` set.
+// d_allow: nullptr = bare search; else bit i of word i/32 says node i may enter the results (not
+// deleted and accepted by the filter): the non-bare path of hnsw_core.hpp:1141-1148.
 int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, uint32_t k, uint32_t ef,
-                       float* d_out_dist, uint64_t* d_out_label, uint32_t* d_out_stats, const HnswSearchWork& work,
-                       hipStream_t stream, std::string* err);
+                       const uint32_t* d_allow, float* d_out_dist, uint64_t* d_out_label, uint32_t* d_out_stats,
+                       const HnswSearchWork& work, hipStream_t stream, std::string* err);
+// out[i] = a[i] & b[i] over `words` u32 (delete flags AND a caller's filter)
+int launch_and_bitmaps(const uint32_t* a, const uint32_t* b, uint32_t* out, uint32_t words, hipStream_t stream);
 
 // ---- brute force (bf_search.hip) ---------------------------------------------------------
 constexpr uint32_t kBfCap = 4096;   // candidate entries per query between two compactions

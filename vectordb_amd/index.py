@@ -154,13 +154,32 @@ class HierarchicalNSW:
         return self._l.vdb_index_device_bytes(self._h)
 
     # ---- searching (gfx950 kernels) ----------------------------------------------
-    def search_batch(self, queries, k: int, stats: bool = False):
+    def labels(self) -> np.ndarray:
+        """External labels in internal-id order (getExternalLabel, hnsw_core.hpp:219-221)."""
+        out = np.empty(self.getElementCount(), np.uint64)
+        check(self._l.vdb_index_labels(self._h, out.ctypes.data_as(_u64p), out.size))
+        return out
+
+    def filter_bitmap(self, filter) -> np.ndarray:
+        """A BaseFilterFunctor's verdicts (hnswlib.hpp:10-23) as the bitmap over internal ids the C-ABI
+        takes.  ``filter``: a callable label -> bool, or a boolean array indexed by internal id."""
+        if callable(filter):
+            ok = np.fromiter((bool(filter(int(l))) for l in self.labels()), bool, self.getElementCount())
+        else:
+            ok = np.asarray(filter, bool)
+            if ok.shape != (self.getElementCount(),):
+                raise ValueError("boolean filter must have one entry per element")
+        return np.packbits(ok, bitorder="little").tobytes().ljust((ok.size + 31) // 32 * 4, b"\0")
+
+    def search_batch(self, queries, k: int, stats: bool = False, filter=None):
         """SearchKNNCloserFirst for every row of `queries`.
 
         numpy in -> numpy out (PCIe-inclusive); torch CUDA tensor in -> torch CUDA tensors
         out, enqueued on torch's current stream with no host synchronisation.
         Returns (dist [nq,k] f32 ascending, label [nq,k] u64/int64) and, with ``stats``,
         a [nq,4] uint32 array {ndis, hops layer 0, hops upper, found}.
+        ``filter``: None, a callable label -> bool, a boolean array over internal ids, or (device
+        path) an int32 CUDA tensor holding the bitmap of ``filter_bitmap``.
         """
         if _is_torch_cuda(queries):
             import torch
@@ -173,22 +192,33 @@ class HierarchicalNSW:
             label = torch.empty((nq, k), dtype=torch.int64, device=q.device)  # same bits as u64
             st = torch.empty((nq, 4), dtype=torch.int32, device=q.device) if stats else None
             stream = torch.cuda.current_stream(q.device).cuda_stream
-            check(self._l.vdb_search_batch_device(self._h, q.data_ptr(), nq, k, dist.data_ptr(), label.data_ptr(),
-                                                  st.data_ptr() if stats else None, stream))
+            allow = None
+            if filter is not None:
+                if _is_torch_cuda(filter):
+                    allow = filter.contiguous()
+                    if allow.dtype != torch.int32 or allow.numel() < (self.getElementCount() + 31) // 32:
+                        raise ValueError("device filter must be an int32 bitmap with ceil(count / 32) words")
+                else:
+                    allow = torch.frombuffer(bytearray(self.filter_bitmap(filter)), dtype=torch.int32).to(q.device)
+            check(self._l.vdb_search_batch_device_filtered(self._h, q.data_ptr(), nq, k,
+                                                           allow.data_ptr() if allow is not None else None,
+                                                           dist.data_ptr(), label.data_ptr(),
+                                                           st.data_ptr() if stats else None, stream))
             return (dist, label, st) if stats else (dist, label)
         q = _as_f32(queries, self.space.dim)
         nq = q.shape[0]
         dist = np.empty((nq, k), np.float32)
         label = np.empty((nq, k), np.uint64)
         st = np.empty((nq, 4), np.uint32) if stats else None
-        check(self._l.vdb_search_batch(self._h, q.ctypes.data_as(_f32p), nq, k, dist.ctypes.data_as(_f32p),
-                                       label.ctypes.data_as(_u64p), st.ctypes.data_as(_u32p) if stats else None))
+        allow = np.frombuffer(self.filter_bitmap(filter), np.uint32) if filter is not None else None
+        check(self._l.vdb_search_batch_filtered(self._h, q.ctypes.data_as(_f32p), nq, k,
+                                                allow.ctypes.data_as(_u32p) if allow is not None else None,
+                                                dist.ctypes.data_as(_f32p), label.ctypes.data_as(_u64p),
+                                                st.ctypes.data_as(_u32p) if stats else None))
         return (dist, label, st) if stats else (dist, label)
 
     def SearchKNNCloserFirst(self, query, k: int, filter=None):  # hnswlib.hpp:87-99
-        if filter is not None:
-            raise VdbError(_lib.VDB_ERR_UNSUPPORTED, "filtered search is not on the device path yet")
-        d, l = self.search_batch(np.asarray(query, np.float32).reshape(1, -1), k)
+        d, l = self.search_batch(np.asarray(query, np.float32).reshape(1, -1), k, filter=filter)
         keep = l[0] != np.uint64(0xFFFFFFFFFFFFFFFF)
         return [(float(a), int(b)) for a, b in zip(d[0][keep], l[0][keep])]
 
