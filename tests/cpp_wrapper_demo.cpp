@@ -47,5 +47,15 @@ int main(int argc, char** argv) {
         auto res = loaded.SearchKNNCloserFirst(x.data() + q * dim, 5);
         for (auto& p : res) std::printf("%zu %a\n", p.second, p.first);
     }
+    // the non-bare path (hnsw_core.hpp:1141-1148): deleted elements and a filter functor
+    for (size_t i = 0; i < 10; ++i) loaded.markDelete(i);
+    struct Mod3 : BaseFilterFunctor {
+        bool operator()(labeltype l) override { return l % 3 == 1; }
+    } mod3;
+    std::puts("filtered");
+    for (size_t q = 0; q < 10; ++q) {
+        auto res = loaded.SearchKNNCloserFirst(x.data() + q * dim, 5, &mod3);
+        for (auto& p : res) std::printf("%zu %a\n", p.second, p.first);
+    }
     return 0;
 }

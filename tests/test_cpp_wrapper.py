@@ -32,7 +32,9 @@ def test_cpp_wrapper_search_matches_oracle(demo, orc, tmp_path):
     path = str(tmp_path / "i.bin")
     r = subprocess.run([demo, "gpu", path], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    got = [(int(a), float.fromhex(b)) for a, b in (line.split() for line in r.stdout.strip().splitlines())]
+    bare_out, filt_out = r.stdout.strip().split("filtered\n")
+    parse = lambda text: [(int(a), float.fromhex(b)) for a, b in (line.split() for line in text.strip().splitlines())]
+    got, got_f = parse(bare_out), parse(filt_out)
     o = orc.OracleHNSW.load(path, orc.L2, 24, mode=orc.TREE64)
     o.set_ef(40)
     # the demo's queries are its first 10 base vectors: read them back from the saved index
@@ -43,3 +45,9 @@ def test_cpp_wrapper_search_matches_oracle(demo, orc, tmp_path):
     res = o.search(x[:10], 5)
     want = [(int(l), float(d)) for ls, ds in zip(res["label"], res["dist"]) for l, d in zip(ls, ds)]
     assert got == want
+    # second half of the demo: labels 0..9 deleted, functor label % 3 == 1
+    for i in range(10):
+        o.mark_delete(i)
+    res = o.search(x[:10], 5, filter_mod=3, filter_keep=1)
+    want_f = [(int(l), float(d)) for ls, ds, c in zip(res["label"], res["dist"], res["count"]) for l, d in zip(ls[:c], ds[:c])]
+    assert got_f == want_f and all(l % 3 == 1 and l >= 10 for l, _ in got_f)

@@ -121,13 +121,34 @@ public:
         sync_device();
         vdb_check(vdb_search_batch(idx_, queries, nq, k, out_dist, out_label, nullptr));
     }
+    // A functor's verdicts (hnswlib.hpp:64-68, called once per element) as the bitmap over internal
+    // ids that the C-ABI takes; evaluate once and reuse it for every batch under the same filter.
+    std::vector<uint32_t> filterBitmap(BaseFilterFunctor& filter) const {
+        const size_t n = getElementCount();
+        std::vector<uint64_t> labels(n);
+        if (n) vdb_check(vdb_index_labels(idx_, labels.data(), n));
+        std::vector<uint32_t> bits((n + 31) / 32 + 1, 0u);
+        for (size_t i = 0; i < n; ++i)
+            if (filter((labeltype)labels[i])) bits[i >> 5] |= 1u << (i & 31);
+        return bits;
+    }
+    // searchKnn(query, k, filter) for nq queries: the non-bare path, hnsw_core.hpp:1141-1148
+    void searchKnnBatchFiltered(const float* queries, size_t nq, size_t k, const uint32_t* allow, float* out_dist,
+                                uint64_t* out_label) const {
+        sync_device();
+        vdb_check(vdb_search_batch_filtered(idx_, queries, nq, k, allow, out_dist, out_label, nullptr));
+    }
     // hnsw_core.hpp:1107-1159: max-heap of (dist, label)
     std::priority_queue<std::pair<float, labeltype>> searchKnn(const void* query, size_t k,
                                                                BaseFilterFunctor* filter = nullptr) const {
-        if (filter) throw std::runtime_error("filtered search is not on the device path yet");
         std::vector<float> d(k);
         std::vector<uint64_t> l(k);
-        searchKnnBatch(static_cast<const float*>(query), 1, k, d.data(), l.data());
+        if (filter) {
+            const std::vector<uint32_t> allow = filterBitmap(*filter);
+            searchKnnBatchFiltered(static_cast<const float*>(query), 1, k, allow.data(), d.data(), l.data());
+        } else {
+            searchKnnBatch(static_cast<const float*>(query), 1, k, d.data(), l.data());
+        }
         std::priority_queue<std::pair<float, labeltype>> out;
         for (size_t i = 0; i < k; ++i)
             if (l[i] != std::numeric_limits<uint64_t>::max()) out.emplace(d[i], (labeltype)l[i]);
