@@ -276,32 +276,36 @@ struct KeyArray {
         }
     }
     // First key with the expanded bit clear, not marked: (id, ordered distance).
+    // (no early exit from the register loops below: a loop left in its middle is not unrolled,
+    // and lo[] indexed by a run-time r moves to scratch memory)
     __device__ __forceinline__ bool peek_candidate(uint32_t& id, uint32_t& dhi) const {
+        bool found = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint64_t open = ballot((lo[r] & 1u) == 0u);
-            if (open) {
+            if (!found && open) {
                 const int p = __builtin_ctzll(open);
                 id = readlane(lo[r], p) >> S;
                 dhi = readlane(hi[r], p);
-                return true;
+                found = true;
             }
         }
-        return false;
+        return found;
     }
     // First key with the expanded bit clear: returns its node id and sets the bit.
     __device__ __forceinline__ bool pop_candidate(int lane, uint32_t& id) {
+        bool found = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint64_t open = ballot((lo[r] & 1u) == 0u);
-            if (open) {
+            if (!found && open) {
                 const int p = __builtin_ctzll(open);
                 id = readlane(lo[r], p) >> S;
                 if (lane == p) lo[r] |= 1u;
-                return true;
+                found = true;
             }
         }
-        return false;
+        return found;
     }
 
     // ---- filtered search (S == 2) only
@@ -330,19 +334,22 @@ struct KeyArray {
     // First key with the expanded bit clear.  An allowed node stays (it is a result) with the bit
     // set; a node that is not allowed was only ever a candidate and leaves the array.
     __device__ __forceinline__ bool pop_candidate_filtered(int lane, uint32_t& id) {
+        bool found = false;
+        uint32_t gone = kEmptyWord;  // index of the entry to erase
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint64_t open = ballot((lo[r] & 1u) == 0u);
-            if (open) {
+            if (!found && open) {
                 const int p = __builtin_ctzll(open);
                 const uint32_t w = readlane(lo[r], p);
                 id = w >> S;
-                if (w & 2u) erase((uint32_t)(r * 64 + p), lane);
+                if (w & 2u) gone = (uint32_t)(r * 64 + p);
                 else if (lane == p) lo[r] |= 1u;
-                return true;
+                found = true;
             }
         }
-        return false;
+        if (gone != kEmptyWord) erase(gone, lane);
+        return found;
     }
     // The result set is the first ef ALLOWED entries.  Full: (bhi, bpos) = distance and index of the
     // ef-th of them (lowerBound of hnsw_core.hpp:348-349); else false.
