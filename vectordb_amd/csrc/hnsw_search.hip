@@ -787,7 +787,13 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
     a.nq = nq;
     a.k = k;
     a.ef = ef;
-    uint32_t need = (uint32_t)(((uint64_t)ef * g.l0stride * 4u + 2u) / 3u), hb = 10;
+    // Visited-set size.  The LDS it takes bounds the queries resident on a CU (160 KiB / table), so
+    // it is sized for what a search typically visits (about ef * maxM0 / 4 nodes on the C2 data,
+    // i.e. half of `need` at the 75 % fill limit), not for the worst case ef * maxM0: a query that
+    // outgrows it is re-run exactly by the large configuration.
+    // (measured on C2, 10 000 queries: ef 100 1.25 ms at 2^12 against 1.59 at 2^11 and 2.33 at 2^13;
+    //  ef 256 3.98 ms at 2^12 against 6.57 at 2^13 and 11.4 at 2^14)
+    uint32_t need = (uint32_t)((uint64_t)ef * g.l0stride / 2u), hb = ef <= 64 ? 11 : 12;
     while ((1u << hb) < need && hb < 14) ++hb;
     a.hbits = hb;
     a.allow = d_allow;
