@@ -46,6 +46,17 @@ def main():
         b.add(x)
         r = b.search(q, 10)
         out[f"{tag}_bf_dist"], out[f"{tag}_bf_label"] = r["dist"], r["label"]
+    # non-bare path (hnsw_core.hpp:1141-1148): every 5th element deleted, functor label % 3 == 1
+    o = orc.OracleHNSW(orc.L2, 16, 256, 4, 32, 100, mode=orc.TREE64)
+    o.add(x)
+    for lab in range(0, 256, 5):
+        o.mark_delete(lab)
+    for ef, k in ((16, 5), (64, 10)):
+        o.set_ef(ef)
+        for fm, tagf in ((0, "del"), (3, "delmod3")):
+            r = o.search(q, k, filter_mod=fm, filter_keep=1)
+            for name in ("dist", "label", "count", "ndis", "nhops0", "nhops_upper"):
+                out[f"nonbare_{tagf}_ef{ef}_k{k}_{name}"] = r[name]
     # inner product, ragged dim
     rng = np.random.default_rng(7)
     xi = rng.standard_normal((200, 24)).astype(np.float32)
