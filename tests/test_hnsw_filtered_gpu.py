@@ -117,3 +117,33 @@ def test_everything_filtered_out(orc):
     assert (l == np.uint64(0xFFFFFFFFFFFFFFFF)).all() and np.isinf(d).all()
     r = o.search(q, 5, filter_mod=1, filter_keep=5)  # label % 1 == 5: never
     assert (r["count"] == 0).all()
+
+
+def test_device_against_committed_golden():
+    """The committed fixtures (tests/golden, tree64 order) straight against the device path: the saved
+    256 x 16 index file, bare searches, then every 5th element deleted with and without the functor."""
+    import os
+    gold_dir = os.path.join(os.path.dirname(__file__), "golden")
+    gold = np.load(os.path.join(gold_dir, "hnsw_golden.npz"))
+    h = vi.HierarchicalNSW(vi.L2Space(16), location=os.path.join(gold_dir, "hnsw_256x16.bin"))
+    q = gold["q"]
+
+    def check(tag, ef, k, flt):
+        h.setefSearch(ef)
+        d, l, st = h.search_batch(q, k, stats=True, filter=flt)
+        np.testing.assert_array_equal(l, gold[f"{tag}_ef{ef}_k{k}_label"].astype(np.uint64))
+        np.testing.assert_array_equal(d.view(np.uint32), gold[f"{tag}_ef{ef}_k{k}_dist"].view(np.uint32))
+        np.testing.assert_array_equal(st[:, 0], gold[f"{tag}_ef{ef}_k{k}_ndis"])
+        np.testing.assert_array_equal(st[:, 1], gold[f"{tag}_ef{ef}_k{k}_nhops0"])
+        np.testing.assert_array_equal(st[:, 2], gold[f"{tag}_ef{ef}_k{k}_nhops_upper"])
+
+    h.to_device(0)
+    for ef in (8, 16, 64):
+        for k in (1, 10):
+            check("tree64", ef, k, None)
+    for lab in range(0, 256, 5):
+        h.markDelete(lab)
+    h.to_device(0)
+    for ef, k in ((16, 5), (64, 10)):
+        check("nonbare_del", ef, k, None)
+        check("nonbare_delmod3", ef, k, lambda lab: lab % 3 == 1)
