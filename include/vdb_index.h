@@ -79,6 +79,15 @@ int vdb_index_add(vdb_index* idx, const float* vec, uint64_t label, int level);
  * inserts concurrently as the reference allows (label stripes, per-node link locks,
  * global lock: hnsw_core.hpp:77-84); the link order is then not reproducible. */
 int vdb_index_add_batch(vdb_index* idx, const float* vecs, const uint64_t* labels, size_t n, int n_threads);
+/* The same insertion with layer 0 built on `device` (no reference counterpart: the
+ * reference builds on host threads only, hnsw_core.hpp:994-1104).  Elements that have upper levels,
+ * and the first 2048 of a new graph, are inserted by the host builder above; the others in lock-free
+ * rounds of search (ef_construction) -> heuristic selection (:357-390) -> reverse links (:392-498) on
+ * the GPU.  Levels, ids and labels are assigned exactly as vdb_index_add_batch does; the links are a
+ * valid HNSW graph but not the sequential builder's graph (a batch has no insertion order).  Leaves
+ * the index uploaded to `device`.  Needs ef_construction <= 256, M <= 32, no deleted elements. */
+int vdb_index_add_batch_device(vdb_index* idx, const float* vecs, const uint64_t* labels, size_t n, int n_threads,
+                               int device);
 /* Summation order used by host-side build distances (default VDB_SUM_TREE64). */
 int vdb_index_set_build_sum_order(vdb_index* idx, int order);
 

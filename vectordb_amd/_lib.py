@@ -32,6 +32,7 @@ SIGNATURES = {
     "vdb_index_free": (None, [_vp]),
     "vdb_index_add": (C.c_int, [_vp, _f32p, C.c_uint64, C.c_int]),
     "vdb_index_add_batch": (C.c_int, [_vp, _f32p, _u64p, C.c_size_t, C.c_int]),
+    "vdb_index_add_batch_device": (C.c_int, [_vp, _f32p, _u64p, C.c_size_t, C.c_int, C.c_int]),
     "vdb_index_set_build_sum_order": (C.c_int, [_vp, C.c_int]),
     "vdb_index_set_ef": (C.c_int, [_vp, C.c_size_t]),
     "vdb_index_mark_delete": (C.c_int, [_vp, C.c_uint64]),

@@ -519,6 +519,126 @@ int vdb_index_add_batch(vdb_index* idx, const float* vecs, const uint64_t* label
     });
 }
 
+// addPoint for a batch with layer 0 built on the device (hnsw_build.hip).  The host (reference
+// algorithm) inserts every element that has upper levels plus a seed of the graph; the rest go in
+// rounds of search -> select -> reverse links on the GPU.
+int vdb_index_add_batch_device(vdb_index* idx, const float* vecs, const uint64_t* labels, size_t n, int n_threads, int device) {
+    return guarded([&] {
+        if (!idx || (!vecs && n)) throw std::invalid_argument("null argument");
+        if (n == 0) return (int)VDB_OK;
+        HostIndex& h = *idx->host;
+        if (h.deleted != 0) throw Unsupported("device graph build with deleted elements in the index");
+        if (h.ef_construction > kMaxEf) throw Unsupported("device graph build needs ef_construction <= 256");
+        if (round_up(h.maxM0, 32) > kMaxL0Stride) throw Unsupported("M above 32 is not supported by the device path");
+        const size_t base = h.append_unlinked(vecs, labels, n);
+        // host part: all elements with upper levels (their layer-0 links included), and enough level-0
+        // ones for the graph to hold kSeed linked elements before the first device round
+        const size_t kSeed = 2048;
+        std::vector<uint32_t> host_ids, dev_ids;
+        size_t linked = base;
+        for (size_t i = 0; i < n; ++i)
+            if (h.levels[base + i] > 0) host_ids.push_back((uint32_t)(base + i));
+        linked += host_ids.size();
+        for (size_t i = 0; i < n; ++i) {
+            if (h.levels[base + i] > 0) continue;
+            if (linked < kSeed) {
+                host_ids.push_back((uint32_t)(base + i));
+                linked += 1;
+            } else {
+                dev_ids.push_back((uint32_t)(base + i));
+            }
+        }
+        h.link_elements(host_ids.data(), host_ids.size(), n_threads);
+        if (dev_ids.empty()) return (int)VDB_OK;
+
+        upload(idx, device);  // vectors of all elements, the links made so far, the finished upper layers
+        DeviceGuard guard(device);
+        const DevGraph& g0 = idx->graph;
+        const uint32_t efc = (uint32_t)h.ef_construction, M = (uint32_t)h.M, maxM0 = (uint32_t)h.maxM0;
+        const size_t total = h.count;
+        const uint32_t max_batch = 32768;
+        DevBuf ident, ids, q, cd, cl, k_in, k_out, v_in, v_out, temp;
+        {
+            std::vector<uint64_t> id64(total);
+            for (size_t i = 0; i < total; ++i) id64[i] = i;
+            ident.alloc(total * 8);
+            VDB_HIP(hipMemcpy(ident.p, id64.data(), total * 8, hipMemcpyHostToDevice));
+        }
+        ids.alloc(dev_ids.size() * 4);
+        VDB_HIP(hipMemcpy(ids.p, dev_ids.data(), dev_ids.size() * 4, hipMemcpyHostToDevice));
+        q.alloc((size_t)max_batch * h.dim * 4);
+        cd.alloc((size_t)max_batch * efc * 4);
+        cl.alloc((size_t)max_batch * efc * 8);
+        BuildWork w;
+        const size_t pair_bytes = (size_t)max_batch * M * 4;
+        k_in.alloc(pair_bytes);
+        k_out.alloc(pair_bytes);
+        v_in.alloc(pair_bytes);
+        v_out.alloc(pair_bytes);
+        w.key_in = (uint32_t*)k_in.p;
+        w.key_out = (uint32_t*)k_out.p;
+        w.val_in = (uint32_t*)v_in.p;
+        w.val_out = (uint32_t*)v_out.p;
+        w.sort_temp_bytes = build_sort_temp_bytes(max_batch * M);
+        temp.alloc(w.sort_temp_bytes);
+        w.sort_temp = temp.p;
+
+        DevGraph gb = g0;  // the search returns internal ids
+        gb.labels = (const uint64_t*)ident.p;
+        uint32_t* links0 = (uint32_t*)idx->links0.p;
+        hipStream_t stream = nullptr;
+        SearchScratch* sc;
+        {
+            std::unique_lock<std::mutex> lock(idx->scratch_lock);
+            sc = &scratch_for(idx, stream, max_batch);
+        }
+        HnswSearchWork work;
+        work.redo = (uint32_t*)sc->redo.p;
+        work.bitmaps = (uint32_t*)sc->bitmaps.p;
+        work.bitmap_words = sc->bitmap_words;
+        std::string err;
+        size_t done = 0;
+        while (done < dev_ids.size()) {
+            // a batch is searched against the graph WITHOUT its own members: keep it a fraction of it
+            size_t nb = std::min<size_t>(std::min<size_t>(max_batch, std::max<size_t>(linked / 4, 64)), dev_ids.size() - done);
+            const uint32_t* bid = (const uint32_t*)ids.p + done;
+            if (launch_gather_rows(g0.vecs, g0.vstride, g0.dim, bid, (uint32_t)nb, (float*)q.p, stream) != 0)
+                throw DeviceError("gather kernel launch failed");
+            int rc = launch_hnsw_search(gb, (const float*)q.p, (uint32_t)nb, efc, efc, nullptr, (float*)cd.p, (uint64_t*)cl.p,
+                                        nullptr, work, stream, &err);
+            if (rc == 0)
+                rc = launch_build_round(gb, links0, (const uint64_t*)cl.p, (const float*)cd.p, bid, (uint32_t)nb, efc, M, maxM0, w,
+                                        stream, &err);
+            if (rc != 0) return set_error(rc, err);
+            done += nb;
+            linked += nb;
+        }
+        VDB_HIP(hipStreamSynchronize(stream));
+        // the device lists are the graph now: write them back in the reference's layout (:259-261, :283-285)
+        const uint32_t ls = g0.l0stride;
+        const size_t chunk = 1 << 16;
+        std::vector<uint32_t> rows(chunk * ls);
+        for (size_t lo = 0; lo < total; lo += chunk) {
+            const size_t m = std::min(chunk, total - lo);
+            VDB_HIP(hipMemcpy(rows.data(), links0 + lo * ls, m * ls * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < m; ++i) {
+                uint32_t* list = h.list0((uint32_t)(lo + i));
+                const uint32_t* r = rows.data() + i * ls;
+                unsigned c = 0;
+                while (c < maxM0 && r[c] != kNoId) ++c;
+                const unsigned char flags = ((const unsigned char*)list)[2];
+                std::memset(list, 0, h.link0_stride);
+                HostIndex::set_list_count(list, c);
+                ((unsigned char*)list)[2] = flags;
+                std::memcpy(list + 1, r, (size_t)c * 4);
+            }
+        }
+        h.version += 1;
+        idx->device_version = h.version;  // the device copy IS this graph
+        return (int)VDB_OK;
+    });
+}
+
 int vdb_index_set_build_sum_order(vdb_index* idx, int order) {
     return guarded([&] {
         if (!idx) throw std::invalid_argument("null index");

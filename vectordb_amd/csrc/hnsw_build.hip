@@ -1,0 +1,260 @@
+// hnsw_build.hip — layer-0 graph construction on the device.
+//
+// Reference: addPoint hnsw_core.hpp:994-1104 = searchBaseLayer (:293-356) at ef_construction,
+// getNeighborsByHeuristic2 (:357-390), mutuallyConnectNewElement (:392-498).  The reference inserts
+// one point at a time under per-node locks.  Here a BATCH of points is inserted per round with no
+// locks, every step a data-parallel kernel:
+//
+//   1. search      the traversal kernel of hnsw_search.hip (ef = k = ef_construction) over the graph
+//                  as it stands, one wave per new point: its ef_construction nearest candidates
+//   2. select      one wave per new point: the heuristic picks <= M of them (a candidate is kept when
+//                  it is closer to the new point than to every neighbour kept so far); the new
+//                  point's own list is written, and one (neighbour, new point) pair per link emitted
+//   3. sort        the pairs by neighbour (rocPRIM radix sort)
+//   4. reverse     one wave per neighbour that gained links: append while the list has room, else the
+//                  same heuristic over (old list + newcomers) as seen from that neighbour (:428-468)
+//
+// Points of one batch do not see each other in step 1 (they meet through step 4), so a batch is kept
+// small against the graph it is added to (the host grows the batch with the graph).  The result is a
+// valid HNSW layer 0 but not the reference's graph bit for bit: insertion order is part of the
+// reference's result and a lock-free batch has none.  It is therefore gated on recall and integrity
+// (tests/test_build_gpu.py), as SURVEY.md §8f prescribes.  Upper layers (1/16 of the points) are
+// built by the host builder first, with the reference algorithm.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>  // rocPRIM's headers call memset without including it
+#include <string>
+
+#include <rocprim/rocprim.hpp>
+
+#include "device_index.hpp"
+#include "launch.hpp"
+#include "traversal_common.hpp"
+
+namespace vdb {
+
+namespace {
+
+using namespace dev;
+
+// out[i][0..dim) = vecs[ids[i]][0..dim): the new points as a query batch
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* vecs, uint32_t vstride, uint32_t dim, const uint32_t* ids,
+                                                          uint32_t n, float* out) {
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* src = vecs + (size_t)ids[i] * vstride;
+    for (uint32_t c = threadIdx.x & 63; c < dim; c += 64) out[(size_t)i * dim + c] = src[c];
+}
+
+// A base row in the register layout score_nodes wants for its query (every 16-lane group a copy).
+template <int NCH>
+__device__ __forceinline__ void load_row_as_query(const DevGraph& g, uint32_t id, int lane, f32x4 (&q)[NCH]) {
+    const int t = lane & 15;
+    const float* row = g.vecs + (size_t)id * g.vstride + 4 * t;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        q[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if ((uint32_t)(64 * j + 4 * t) < g.vstride) q[j] = *reinterpret_cast<const f32x4*>(row + 64 * j);
+    }
+}
+
+// getNeighborsByHeuristic2 (:357-390) over candidates sorted closest first (c_id / c_d in LDS, c_d =
+// ordered distance to the centre).  Returns the number kept; lane j < kept holds the j-th kept id.
+template <int NCH, int GPB, bool IS_L2>
+__device__ __forceinline__ uint32_t select_heuristic(const DevGraph& g, const uint32_t* c_id, const uint32_t* c_d, uint32_t n_c,
+                                                     uint32_t m, int lane, uint32_t& keep_id) {
+    keep_id = kNoId;
+    uint32_t nk = 0;
+#pragma unroll 1
+    for (uint32_t i = 0; i < n_c && nk < m; ++i) {
+        const uint32_t c = c_id[i], cd = c_d[i];
+        bool good = true;
+        if (nk) {
+            f32x4 qc[NCH];
+            load_row_as_query<NCH>(g, c, lane, qc);
+            uint32_t d = score_nodes<NCH, GPB, IS_L2>(g, qc, keep_id, nk, lane);
+            good = ballot((uint32_t)lane < nk && d < cd) == 0ull;  // :375-381: closer to a kept neighbour than to the centre
+        }
+        if (good) {
+            if ((uint32_t)lane == nk) keep_id = c;
+            nk += 1;
+        }
+    }
+    return nk;
+}
+
+struct SelectArgs {
+    DevGraph g;
+    uint32_t* links0;            // the graph's layer-0 lists, written here
+    const uint64_t* cand_label;  // [nb][efc] internal ids (the search ran with identity labels), closest first
+    const float* cand_dist;      // [nb][efc]
+    const uint32_t* new_ids;     // [nb]
+    uint32_t nb, efc, M;
+    uint32_t* pair_key;          // [nb * M] neighbour that gains a link (all ones: none)
+    uint32_t* pair_val;          // [nb * M] the new point
+};
+
+template <int NCH, int GPB, bool IS_L2>
+__global__ __launch_bounds__(64) void build_select_kernel(SelectArgs a) {
+    __shared__ uint32_t c_id[kMaxEf], c_d[kMaxEf];
+    const int lane = lane_id();
+    const uint32_t b = blockIdx.x;
+    const uint32_t me = a.new_ids[b];
+    uint32_t n_c = 0;
+    for (uint32_t i0 = 0; i0 < a.efc; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const uint64_t lab = i < a.efc ? a.cand_label[(size_t)b * a.efc + i] : ~0ull;
+        const bool ok = lab != ~0ull;
+        if (ok) {
+            c_id[i] = (uint32_t)lab;
+            c_d[i] = f2ord(a.cand_dist[(size_t)b * a.efc + i]);
+        }
+        n_c += (uint32_t)__builtin_popcountll(ballot(ok));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t keep_id;
+    const uint32_t nk = select_heuristic<NCH, GPB, IS_L2>(a.g, c_id, c_d, n_c, a.M, lane, keep_id);
+    // own list, farthest first / closest last as the reference drains its heap (:404-420)
+    const uint32_t src = nk ? (nk - 1u - (uint32_t)lane) & 63u : 0u;
+    const uint32_t v = bpermute(keep_id, (int)src);
+    if ((uint32_t)lane < a.g.l0stride) a.links0[(size_t)me * a.g.l0stride + lane] = (uint32_t)lane < nk ? v : kNoId;
+    if ((uint32_t)lane < a.M) {
+        a.pair_key[(size_t)b * a.M + lane] = (uint32_t)lane < nk ? keep_id : kEmptyWord;
+        a.pair_val[(size_t)b * a.M + lane] = me;
+    }
+}
+
+struct ReverseArgs {
+    DevGraph g;
+    uint32_t* links0;
+    const uint32_t* key;  // sorted: neighbour ids, all-ones at the end
+    const uint32_t* val;  // the new points, in step with key
+    uint32_t n_pairs, maxM0;
+};
+
+// One wave per run of equal keys (the block at the head of the run does the work).
+template <int NCH, int GPB, bool IS_L2>
+__global__ __launch_bounds__(64) void build_reverse_kernel(ReverseArgs a) {
+    __shared__ uint32_t c_id[64], c_d[64];
+    __shared__ uint64_t s_key[64];
+    const int lane = lane_id();
+    const uint32_t i = blockIdx.x;
+    const uint32_t nb = a.key[i];
+    if (nb == kEmptyWord || (i > 0 && a.key[i - 1] == nb)) return;
+    // newcomers of this neighbour: at most 32 are taken (a hub that gains more in one batch keeps the
+    // first 32 in sort order; the others still link TO it)
+    const bool mine = (uint32_t)lane < 32u && i + lane < a.n_pairs && a.key[i + lane] == nb;
+    const uint64_t mm = ballot(mine);
+    const uint32_t t = (uint32_t)__builtin_ctzll(~mm);  // length of the run of ones from lane 0
+    const uint32_t add = (uint32_t)lane < t ? a.val[i + lane] : kNoId;
+    const uint32_t ls = a.g.l0stride;
+    const uint32_t cur = (uint32_t)lane < ls ? a.links0[(size_t)nb * ls + lane] : kNoId;
+    const uint32_t c = (uint32_t)__builtin_popcountll(ballot(cur != kNoId));  // lists are packed to the front
+    if (c + t <= a.maxM0) {  // room: append (:424-427)
+        if ((uint32_t)lane < t) a.links0[(size_t)nb * ls + c + lane] = add;
+        return;
+    }
+    // full: the heuristic over old list + newcomers, seen from nb (:428-468)
+    const uint32_t shifted = bpermute(add, (lane - (int)c) & 63);
+    const uint32_t pool = (uint32_t)lane < c ? cur : ((uint32_t)lane < c + t ? shifted : kNoId);
+    const uint32_t n_pool = c + t;  // <= 64
+    f32x4 qn[NCH];
+    load_row_as_query<NCH>(a.g, nb, lane, qn);
+    uint32_t d = kEmptyWord;
+    {
+        const uint32_t m0 = n_pool < 32u ? n_pool : 32u;
+        const uint32_t d0 = score_nodes<NCH, GPB, IS_L2>(a.g, qn, pool, m0, lane);
+        if ((uint32_t)lane < m0) d = d0;
+        if (n_pool > 32u) {
+            const uint32_t ids_hi = bpermute(pool, (lane + 32) & 63);
+            const uint32_t d1 = score_nodes<NCH, GPB, IS_L2>(a.g, qn, ids_hi, n_pool - 32u, lane);
+            const uint32_t d1s = bpermute(d1, (lane - 32) & 63);
+            if ((uint32_t)lane >= 32u && (uint32_t)lane < n_pool) d = d1s;
+        }
+    }
+    // sort the pool closest first (rank by counting; equal distances: larger id first, :363-366)
+    const uint64_t k = ((uint64_t)d << 32) | (uint32_t)~pool;
+    s_key[lane] = (uint32_t)lane < n_pool ? k : ~0ull;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n_pool; ++j) rank += s_key[j] < k ? 1u : 0u;
+    if ((uint32_t)lane < n_pool) {
+        c_id[rank] = pool;
+        c_d[rank] = d;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t keep_id;
+    const uint32_t nk = select_heuristic<NCH, GPB, IS_L2>(a.g, c_id, c_d, n_pool, a.maxM0, lane, keep_id);
+    const uint32_t src = nk ? (nk - 1u - (uint32_t)lane) & 63u : 0u;
+    const uint32_t v = bpermute(keep_id, (int)src);
+    if ((uint32_t)lane < ls) a.links0[(size_t)nb * ls + lane] = (uint32_t)lane < nk ? v : kNoId;
+}
+
+template <int NCH, int GPB>
+void launch_select(const SelectArgs& a, hipStream_t s) {
+    if (a.g.metric == 0) hipLaunchKernelGGL((build_select_kernel<NCH, GPB, true>), dim3(a.nb), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((build_select_kernel<NCH, GPB, false>), dim3(a.nb), dim3(64), 0, s, a);
+}
+template <int NCH, int GPB>
+void launch_reverse(const ReverseArgs& a, hipStream_t s) {
+    if (a.g.metric == 0) hipLaunchKernelGGL((build_reverse_kernel<NCH, GPB, true>), dim3(a.n_pairs), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((build_reverse_kernel<NCH, GPB, false>), dim3(a.n_pairs), dim3(64), 0, s, a);
+}
+
+}  // namespace
+
+size_t build_sort_temp_bytes(uint32_t max_pairs) {
+    size_t bytes = 0;
+    uint32_t* p = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, p, p, p, p, (size_t)max_pairs, 0, 32, nullptr);
+    return bytes;
+}
+
+int launch_gather_rows(const float* d_vecs, uint32_t vstride, uint32_t dim, const uint32_t* d_ids, uint32_t n, float* d_out,
+                       hipStream_t stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, d_vecs, vstride, dim, d_ids, n, d_out);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+int launch_build_round(const DevGraph& g, uint32_t* d_links0, const uint64_t* d_cand_label, const float* d_cand_dist,
+                       const uint32_t* d_new_ids, uint32_t nb, uint32_t efc, uint32_t M, uint32_t maxM0, const BuildWork& w,
+                       hipStream_t stream, std::string* err) {
+    if (nb == 0) return 0;
+    if (efc > kMaxEf || M > 64 || g.l0stride > kMaxL0Stride || maxM0 > g.l0stride) {
+        if (err) *err = "device graph build: ef_construction above 256 or M above 32 is not supported";
+        return 4;
+    }
+    const uint32_t n_pairs = nb * M;
+    SelectArgs sa{g, d_links0, d_cand_label, d_cand_dist, d_new_ids, nb, efc, M, w.key_in, w.val_in};
+    const uint32_t nch = (g.vstride + 63u) / 64u;
+    if (nch <= 1) launch_select<1, 8>(sa, stream);
+    else if (nch <= 2) launch_select<2, 8>(sa, stream);
+    else if (nch <= 4) launch_select<4, 4>(sa, stream);
+    else if (nch <= 8) launch_select<8, 2>(sa, stream);
+    else launch_select<16, 1>(sa, stream);
+    hipError_t e = hipGetLastError();
+    size_t temp = w.sort_temp_bytes;
+    if (e == hipSuccess)
+        e = rocprim::radix_sort_pairs(w.sort_temp, temp, w.key_in, w.key_out, w.val_in, w.val_out, (size_t)n_pairs, 0, 32, stream);
+    if (e == hipSuccess) {
+        ReverseArgs ra{g, d_links0, w.key_out, w.val_out, n_pairs, maxM0};
+        if (nch <= 1) launch_reverse<1, 8>(ra, stream);
+        else if (nch <= 2) launch_reverse<2, 8>(ra, stream);
+        else if (nch <= 4) launch_reverse<4, 4>(ra, stream);
+        else if (nch <= 8) launch_reverse<8, 2>(ra, stream);
+        else launch_reverse<16, 1>(ra, stream);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        if (err) *err = std::string("device graph build failed: ") + hipGetErrorString(e);
+        return 3;
+    }
+    return 0;
+}
+
+}  // namespace vdb

@@ -39,149 +39,13 @@
 
 #include "device_index.hpp"
 #include "launch.hpp"
+#include "traversal_common.hpp"
 
 namespace vdb {
 
 namespace {
 
-constexpr uint32_t kEmptyWord = 0xFFFFFFFFu;
-
-// ------------------------------------------------------------------ lane primitives
-
-__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, 0xF, false);
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_f32(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
-constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
-constexpr int kDppHalfMirror = 0x141;  // lane i <- lane 7-i inside each 8
-constexpr int kDppMirror = 0x140;      // lane i <- lane 15-i inside each 16
-constexpr int kDppWaveShr1 = 0x138;    // lane i <- lane i-1 over the whole wave
-constexpr int kDppWaveShl1 = 0x130;    // lane i <- lane i+1 over the whole wave
-
-__device__ __forceinline__ uint32_t readlane(uint32_t v, int lane) {
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
-}
-__device__ __forceinline__ uint32_t bpermute(uint32_t v, int src_lane) {
-    return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
-}
-__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-
-// float bits -> unsigned with the same order (and back).  -0.0 never occurs (sums of
-// squares start from +0; 1 - x rounds to +0), NaN inputs are outside the contract.
-__device__ __forceinline__ uint32_t f2ord(float f) {
-    uint32_t u = __builtin_bit_cast(uint32_t, f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(uint32_t u) {
-    return __builtin_bit_cast(float, (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
-}
-
-// minimum of v over the 64 lanes, returned wave-uniform: xor butterfly inside each row of 16
-// (DPP), then the four rows through SGPRs
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-    uint32_t o;
-    o = dpp_u32<kDppXor1>(v, v);
-    v = o < v ? o : v;
-    o = dpp_u32<kDppXor2>(v, v);
-    v = o < v ? o : v;
-    o = dpp_u32<kDppHalfMirror>(v, v);
-    v = o < v ? o : v;
-    o = dpp_u32<kDppMirror>(v, v);
-    v = o < v ? o : v;
-    const uint32_t a = readlane(v, 0), b = readlane(v, 16), c = readlane(v, 32), d = readlane(v, 48);
-    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
-    return ab < cd ? ab : cd;
-}
-
-// ------------------------------------------------------------------ distance engine
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-// Scores up to 32 nodes.  In: lane r (< m) holds node id ids[r].  Out: lane r (< m) holds
-// the ordered-u32 distance of node r; the other lanes hold garbage.
-// NCH = number of 64-float chunks per row that are touched; GPB = 16-lane groups whose
-// loads are issued before the first FMA (4 nodes each).
-template <int NCH, bool IS_L2>
-__device__ __forceinline__ uint32_t group_distance(const f32x4 (&q)[NCH], const f32x4 (&x)[NCH]) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if constexpr (IS_L2) {
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const float d0 = q[j].x - x[j].x, d1 = q[j].y - x[j].y;
-            const float d2 = q[j].z - x[j].z, d3 = q[j].w - x[j].w;
-            a0 = __builtin_fmaf(d0, d0, a0);
-            a1 = __builtin_fmaf(d1, d1, a1);
-            a2 = __builtin_fmaf(d2, d2, a2);
-            a3 = __builtin_fmaf(d3, d3, a3);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            a0 = __builtin_fmaf(q[j].x, x[j].x, a0);
-            a1 = __builtin_fmaf(q[j].y, x[j].y, a1);
-            a2 = __builtin_fmaf(q[j].z, x[j].z, a2);
-            a3 = __builtin_fmaf(q[j].w, x[j].w, a3);
-        }
-    }
-    // pairwise tree over the 64 virtual lanes: 2 levels in-lane, 4 across lanes
-    float s = (a0 + a1) + (a2 + a3);
-    s = s + dpp_f32<kDppXor1>(s);
-    s = s + dpp_f32<kDppXor2>(s);
-    s = s + dpp_f32<kDppHalfMirror>(s);
-    s = s + dpp_f32<kDppMirror>(s);
-    if constexpr (!IS_L2) s = 1.0f - s;
-    return f2ord(s);
-}
-
-template <int NCH, int GPB, bool IS_L2>
-__device__ __forceinline__ uint32_t score_nodes(const DevGraph& g, const f32x4 (&q)[NCH], uint32_t ids, uint32_t m,
-                                                int lane) {
-    const int grp = lane >> 4, t = lane & 15;
-    const uint32_t vstride = g.vstride;
-    uint32_t out = kEmptyWord;
-    const uint32_t ngroups = (m + 3u) >> 2;
-#pragma unroll 1
-    for (uint32_t base = 0; base < ngroups; base += GPB) {
-        // node ids of every group first (independent cross-lane reads, one wait), then all the
-        // row loads back to back, then the arithmetic
-        uint32_t nid[GPB];
-#pragma unroll
-        for (int b = 0; b < GPB; ++b) nid[b] = bpermute(ids, (int)((4u * (base + b) + (uint32_t)grp) & 63u));
-        f32x4 x[GPB][NCH];
-#pragma unroll
-        for (int b = 0; b < GPB; ++b) {
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) x[b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (4u * (base + b) + (uint32_t)grp < m) {
-                const float* row = g.vecs + (size_t)nid[b] * vstride + 4 * t;
-#pragma unroll
-                for (int j = 0; j < NCH; ++j)
-                    if ((uint32_t)(64 * j + 4 * t) < vstride) x[b][j] = *reinterpret_cast<const f32x4*>(row + 64 * j);
-            }
-        }
-        // Group b's result (the same in its 16 lanes) is kept by lane t == b of each group ...
-        uint32_t keep = kEmptyWord;
-#pragma unroll
-        for (int b = 0; b < GPB; ++b) {
-            if (base + b < ngroups) {  // wave-uniform
-                const uint32_t so0 = group_distance<NCH, IS_L2>(q, x[b]);
-                if (t == b) keep = so0;
-            }
-        }
-        // ... and node r = 4 (base + b) + g is handed to lane r in one cross-lane read
-        const uint32_t rl = (uint32_t)lane - 4u * base;  // r relative to this batch
-        const uint32_t v = bpermute(keep, (int)((16u * (rl & 3u) + (rl >> 2)) & 63u));
-        if (rl < 4u * GPB) out = v;
-    }
-    return out;
-}
+using namespace dev;
 
 // ------------------------------------------------------------------ visited set
 

@@ -321,8 +321,9 @@ void HostIndex::add(const float* v, uint64_t label, int level) {
     add_batch(v, &l, 1, 1, level);
 }
 
-void HostIndex::add_batch(const float* vecs, const uint64_t* labels, size_t n, int n_threads, int forced_level) {
-    if (n == 0) return;
+// Ids, levels and rows of n new elements, assigned in input order exactly as n sequential addPoint
+// calls would (:1018-1043); nothing is linked yet.  Returns the first new id.
+size_t HostIndex::append_unlinked(const float* vecs, const uint64_t* labels, size_t n, int forced_level) {
     const size_t base = count;
     if (base + n > capacity) throw std::runtime_error("The number of elements exceeds the specified limit");  // :1018-1020
     {
@@ -335,24 +336,25 @@ void HostIndex::add_batch(const float* vecs, const uint64_t* labels, size_t n, i
         }
         for (size_t i = 0; i < n; ++i) label_map_[labels ? labels[i] : (uint64_t)(base + i)] = (uint32_t)(base + i);
     }
-    // ids, levels, rows: assigned in input order, exactly as n sequential addPoint calls
-    std::vector<int> lv(n);
     for (size_t i = 0; i < n; ++i) {
-        lv[i] = draw_level();  // drawn even when overridden, as :1028-1029
-        if (forced_level > 0) lv[i] = forced_level;
-    }
-    for (size_t i = 0; i < n; ++i) {
+        int lv = draw_level();  // drawn even when overridden, as :1028-1029
+        if (forced_level > 0) lv = forced_level;
         const uint32_t id = (uint32_t)(base + i);
         char* r = row(id);
         std::memset(r, 0, stride);  // :1039
         const uint64_t l = labels ? labels[i] : (uint64_t)(base + i);
         std::memcpy(r + label_off, &l, 8);
         std::memcpy(r + data_off, vecs + i * dim, data_size);
-        levels[id] = lv[i];
+        levels[id] = lv;
     }
     count = base + n;
     ++version;
+    return base;
+}
 
+// addPoint's linking (:1044-1103) for elements that append_unlinked stored, in the order given.
+void HostIndex::link_elements(const uint32_t* ids, size_t n, int n_threads) {
+    if (n == 0) return;
     std::atomic<size_t> next{0};
     std::atomic<bool> failed{false};
     std::string err;
@@ -363,7 +365,7 @@ void HostIndex::add_batch(const float* vecs, const uint64_t* labels, size_t n, i
             for (;;) {
                 const size_t i = next.fetch_add(1);
                 if (i >= n || failed.load()) break;
-                insert((uint32_t)(base + i), vecs + i * dim, lv[i], sc);
+                insert(ids[i], vec(ids[i]), levels[ids[i]], sc);
             }
         } catch (const std::exception& e) {
             std::unique_lock<std::mutex> g(err_lock);
@@ -375,16 +377,25 @@ void HostIndex::add_batch(const float* vecs, const uint64_t* labels, size_t n, i
         worker();
     } else {
         // the very first element of an empty index goes in alone (it only sets the entry)
-        if (base == 0) {
+        if (entry == 0xFFFFFFFFu) {
             BuildScratch sc;
-            insert(0, vecs, lv[0], sc);
+            insert(ids[0], vec(ids[0]), levels[ids[0]], sc);
             next = 1;
         }
         std::vector<std::thread> pool;
         for (int t = 0; t < n_threads; ++t) pool.emplace_back(worker);
         for (auto& th : pool) th.join();
     }
+    ++version;
     if (failed) throw std::runtime_error(err);
+}
+
+void HostIndex::add_batch(const float* vecs, const uint64_t* labels, size_t n, int n_threads, int forced_level) {
+    if (n == 0) return;
+    const size_t base = append_unlinked(vecs, labels, n, forced_level);
+    std::vector<uint32_t> ids(n);
+    for (size_t i = 0; i < n; ++i) ids[i] = (uint32_t)(base + i);
+    link_elements(ids.data(), n, n_threads);
 }
 
 // ------------------------------------------------------------------------------ persistence

@@ -81,6 +81,9 @@ public:
 
     void add(const float* vec, uint64_t label, int level);
     void add_batch(const float* vecs, const uint64_t* labels, size_t n, int n_threads, int forced_level = -1);
+    // the two halves of add_batch, for the device builder (hnsw_build.hip): store, then link a subset on the host
+    size_t append_unlinked(const float* vecs, const uint64_t* labels, size_t n, int forced_level = -1);
+    void link_elements(const uint32_t* ids, size_t n, int n_threads);
     void save(const std::string& path) const;
     void mark_delete(uint64_t label, bool undo);
     void resize(size_t new_capacity);

@@ -32,6 +32,22 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
 // out[i] = a[i] & b[i] over `words` u32 (delete flags AND a caller's filter)
 int launch_and_bitmaps(const uint32_t* a, const uint32_t* b, uint32_t* out, uint32_t words, hipStream_t stream);
 
+// ---- layer-0 graph construction (hnsw_build.hip) --------------------------------------------
+struct BuildWork {
+    uint32_t *key_in = nullptr, *val_in = nullptr, *key_out = nullptr, *val_out = nullptr;  // [max batch * M] each
+    void* sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
+};
+size_t build_sort_temp_bytes(uint32_t max_pairs);
+// out[i][0..dim) = vecs[ids[i]][0..dim)
+int launch_gather_rows(const float* d_vecs, uint32_t vstride, uint32_t dim, const uint32_t* d_ids, uint32_t n, float* d_out,
+                       hipStream_t stream);
+// One insertion round after the search: neighbour selection for the nb new points (candidates =
+// the search's output with identity labels), their lists, and the reverse links.  See hnsw_build.hip.
+int launch_build_round(const DevGraph& g, uint32_t* d_links0, const uint64_t* d_cand_label, const float* d_cand_dist,
+                       const uint32_t* d_new_ids, uint32_t nb, uint32_t efc, uint32_t M, uint32_t maxM0, const BuildWork& w,
+                       hipStream_t stream, std::string* err);
+
 // ---- brute force (bf_search.hip) ---------------------------------------------------------
 constexpr uint32_t kBfCap = 4096;   // candidate entries per query between two compactions
 constexpr uint32_t kBfMaxK = 1024;

@@ -99,6 +99,17 @@ class HierarchicalNSW:
             lp = labels.ctypes.data_as(_u64p)
         check(self._l.vdb_index_add_batch(self._h, v.ctypes.data_as(_f32p), lp, v.shape[0], n_threads))
 
+    def add_items_device(self, vecs, labels=None, n_threads: int = 1, device: int = 0) -> None:
+        """add_items with layer 0 built on the GPU (include/vdb_index.h, vdb_index_add_batch_device);
+        the index is left uploaded to ``device``."""
+        v = _as_f32(vecs, self.space.dim)
+        lab = None if labels is None else np.ascontiguousarray(labels, np.uint64)
+        if lab is not None and lab.shape != (v.shape[0],):
+            raise ValueError("one label per vector")
+        check(self._l.vdb_index_add_batch_device(self._h, v.ctypes.data_as(_f32p), None if lab is None else lab.ctypes.data_as(_u64p),
+                                                 v.shape[0], n_threads, device))
+        self._device = device
+
     def set_build_sum_order(self, order: int) -> None:
         check(self._l.vdb_index_set_build_sum_order(self._h, order))
 
