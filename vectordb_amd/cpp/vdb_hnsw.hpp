@@ -95,6 +95,11 @@ public:
         vdb_check(vdb_index_add_batch(idx_, vecs, labels, n, n_threads));
         dirty_ = true;
     }
+    // the same insertion with layer 0 built on the GPU (include/vdb_index.h); leaves the index uploaded
+    void addPointsDevice(const float* vecs, const uint64_t* labels, size_t n, int n_threads) {
+        vdb_check(vdb_index_add_batch_device(idx_, vecs, labels, n, n_threads, device_));
+        dirty_ = false;
+    }
     void saveIndex(const std::string& location) override { vdb_check(vdb_index_save(idx_, location.c_str())); }
     void setefSearch(size_t ef) { vdb_check(vdb_index_set_ef(idx_, ef)); }
     size_t getCapacity() const { return vdb_index_capacity(idx_); }
