@@ -98,6 +98,13 @@ size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 // Per-stream scratch of the traversal (work list of re-run queries + visited bitmaps).
 struct SearchScratch {
     DevBuf redo, bitmaps, allow;  // allow: delete flags AND the caller's filter, when both exist
+    // host-mapped {re-run queries, nq} written by the last launch on this stream, and the ef it ran at:
+    // read (without synchronising) before the next launch to size the visited set (see search_device)
+    uint32_t* report = nullptr;
+    uint32_t report_ef = 0;
+    ~SearchScratch() {
+        if (report) (void)hipHostFree(report);
+    }
     size_t redo_cap = 0;
     uint32_t bitmap_words = 0;
 };
@@ -112,6 +119,7 @@ struct vdb_index {
     DevGraph graph{};
     DevBuf vecs, links0, upper_row, upper_links, labels;
     DevBuf live;  // bit i = element i is not deleted; allocated only when the upload saw deleted elements
+    std::map<uint32_t, uint32_t> hbits_bias;  // per ef: extra log2 of the visited-set size (guarded by scratch_lock)
     std::mutex scratch_lock;
     std::map<hipStream_t, std::unique_ptr<SearchScratch>> scratch;
 
@@ -411,10 +419,33 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
             allow = (const uint32_t*)s.allow.p;
         }
     }
+    // The LDS visited set is sized for a typical search (hnsw_search.hip); what "typical" is depends on
+    // the data.  Each launch reports how many queries outgrew it; when that was more than 2 % the
+    // next launches at this ef get a table twice the size (sticky, at most 2^14 entries).
+    if (!s.report) {
+        VDB_HIP(hipHostMalloc((void**)&s.report, 8, hipHostMallocMapped));
+        s.report[0] = s.report[1] = 0;
+    }
+    {
+        const uint32_t redone = ((volatile uint32_t*)s.report)[0], of = ((volatile uint32_t*)s.report)[1];
+        if (of != 0 && s.report_ef != 0) {
+            if ((uint64_t)redone * 50u > of) {
+                uint32_t& b = idx->hbits_bias[s.report_ef];
+                if (b < 3) b += 1;
+            }
+            ((volatile uint32_t*)s.report)[1] = 0;  // one observation per launch
+        }
+    }
     HnswSearchWork work;
     work.redo = (uint32_t*)s.redo.p;
     work.bitmaps = (uint32_t*)s.bitmaps.p;
     work.bitmap_words = s.bitmap_words;
+    work.report = s.report;
+    {
+        auto it = idx->hbits_bias.find((uint32_t)ef);
+        work.hbits_bias = it == idx->hbits_bias.end() ? 0u : it->second;
+    }
+    s.report_ef = (uint32_t)ef;
     if (fail_word) *fail_word = work.redo + 1;
     std::string err;
     const int rc = launch_hnsw_search(idx->graph, d_queries, (uint32_t)nq, (uint32_t)k, (uint32_t)ef, allow, d_out_dist,

@@ -260,6 +260,7 @@ struct SearchArgs {
     const uint32_t* allow; // filtered search: bit i of word i/32 = node i may enter the results
     uint32_t* redo;        // [0] = count, [1] = queries that could not be answered, [2 + i] = query ids to re-run
     uint32_t* bitmaps;     // large configuration: [gridDim.x][bitmap_words]
+    uint32_t* report;      // nullable, host-mapped: [0] = queries the fast configuration gave up on, [1] = nq
     uint32_t bitmap_words;
 };
 
@@ -284,6 +285,12 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
     }
 
     const uint32_t n_work = LARGE ? a.redo[0] : a.nq;
+    if constexpr (LARGE) {  // tells the host how the visited-set size chosen for this launch fared
+        if (blockIdx.x == 0 && lane == 0 && a.report) {
+            a.report[0] = n_work;
+            a.report[1] = a.nq;
+        }
+    }
 #pragma unroll 1
     for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {
         const uint32_t qi = LARGE ? a.redo[2 + w] : w;
@@ -616,9 +623,13 @@ int launch_r(const SearchArgs& a, hipStream_t stream, std::string* err) {
         if (a.ef <= 128) return launch_cfg<NCH, GPB, 4, 16, true>(a, stream, err);
         return launch_cfg<NCH, GPB, 8, 16, true>(a, stream, err);
     }
-    if (a.ef <= 64) return launch_cfg<NCH, GPB, 1, 2, false>(a, stream, err);
-    if (a.ef <= 128) return launch_cfg<NCH, GPB, 2, 4, false>(a, stream, err);
-    return launch_cfg<NCH, GPB, 4, 8, false>(a, stream, err);
+    // capacity 64 R > ef: with capacity == ef every tie at the bound that is pushed off the end sends
+    // its query to the large configuration (measured on the C4 data: ef 64 took 13.4 ms against 7.4 ms
+    // at ef 62 and at ef 65)
+    if (a.ef <= 60) return launch_cfg<NCH, GPB, 1, 2, false>(a, stream, err);
+    if (a.ef <= 124) return launch_cfg<NCH, GPB, 2, 4, false>(a, stream, err);
+    if (a.ef <= 252) return launch_cfg<NCH, GPB, 4, 8, false>(a, stream, err);
+    return launch_cfg<NCH, GPB, 5, 10, false>(a, stream, err);
 }
 
 }  // namespace
@@ -659,6 +670,8 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
     //  ef 256 3.98 ms at 2^12 against 6.57 at 2^13 and 11.4 at 2^14)
     uint32_t need = (uint32_t)((uint64_t)ef * g.l0stride / 2u), hb = ef <= 64 ? 11 : 12;
     while ((1u << hb) < need && hb < 14) ++hb;
+    hb += work.hbits_bias;  // raised by the caller when earlier launches at this ef overflowed often
+    if (hb > 14) hb = 14;
     a.hbits = hb;
     a.allow = d_allow;
     a.out_dist = d_out_dist;
@@ -667,6 +680,7 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
     a.redo = work.redo;
     a.bitmaps = work.bitmaps;
     a.bitmap_words = work.bitmap_words;
+    a.report = work.report;
     hipError_t e = hipMemsetAsync(work.redo, 0, 2 * sizeof(uint32_t), stream);
     if (e != hipSuccess) {
         if (err) *err = std::string("hipMemsetAsync: ") + hipGetErrorString(e);

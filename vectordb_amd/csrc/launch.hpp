@@ -16,6 +16,8 @@ constexpr uint32_t kMaxL0Stride = 64;      // layer-0 list slots (maxM0 <= 64, i
 constexpr uint32_t kLargeBlocks = 128;     // resident waves of the large configuration (one bitmap each)
 
 struct HnswSearchWork {
+    uint32_t* report = nullptr;   // nullable, host-mapped [2]: {queries re-run by the large configuration, nq} of this launch
+    uint32_t hbits_bias = 0;      // added to log2 of the visited-set size the launcher picks
     uint32_t* redo = nullptr;     // [2 + nq] u32; [0] (re-run count) and [1] (unanswerable filtered queries) zeroed by the launcher
     uint32_t* bitmaps = nullptr;  // [kLargeBlocks][bitmap_words]
     uint32_t bitmap_words = 0;

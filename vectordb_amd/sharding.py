@@ -24,8 +24,9 @@ def shard_range(n: int, world: int, rank: int) -> tuple[int, int]:
 
 
 def build_shard(base: np.ndarray, world: int, rank: int, metric: int, M: int = 16, ef_construction: int = 200,
-                n_threads: int = 1):
-    """HierarchicalNSW over this rank's rows, labels = global row ids, seed 100 + rank."""
+                n_threads: int = 1, device_build: int | None = None):
+    """HierarchicalNSW over this rank's rows, labels = global row ids, seed 100 + rank.
+    ``device_build`` = a device ordinal: layer 0 is linked on that GPU (index.add_items_device)."""
     from . import index as vi
 
     lo, hi = shard_range(base.shape[0], world, rank)
@@ -33,7 +34,11 @@ def build_shard(base: np.ndarray, world: int, rank: int, metric: int, M: int = 1
     space = vi.L2Space(dim) if metric == vi.L2 else vi.InnerProductSpace(dim)
     h = vi.HierarchicalNSW(space, max(hi - lo, 1), M, ef_construction, 100 + rank)
     if hi > lo:
-        h.add_items(base[lo:hi], np.arange(lo, hi, dtype=np.uint64), n_threads=n_threads)
+        labels = np.arange(lo, hi, dtype=np.uint64)
+        if device_build is None:
+            h.add_items(base[lo:hi], labels, n_threads=n_threads)
+        else:
+            h.add_items_device(base[lo:hi], labels, n_threads=n_threads, device=device_build)
     return h
 
 
