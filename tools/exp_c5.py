@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4] (C5) on ONE GPU: 100M x 128 fp32 (51.2 GB of vectors, 65 GB device image),
+k=100.  Graph built on the device, 10 000-query batches, recall@100 against exact brute force on the
+first 1 000 queries.  Not part of bench.py; results go to profiles/."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vectordb_amd import datasets, index as vi
+
+n = int(os.environ.get("EXP_N", 100_000_000)); dim, nq, k, nt = 128, 10_000, 100, 1000
+law = datasets.ClusteredLaw(dim, latent=32)
+t0 = time.time()
+base = np.empty((n, dim), np.float32)
+step = 10_000_000
+for lo in range(0, n, step):           # chunks with their own seeds: progress lines, same law
+    m = min(step, n - lo)
+    base[lo:lo + m] = law.sample(m, seed=1000 + lo // step)
+    print(f"data {lo + m}/{n} rows, {time.time() - t0:.0f}s", flush=True)
+q = law.sample(nq, seed=2)
+dq = torch.from_numpy(q).cuda()
+
+t0 = time.time()
+bf = vi.BruteforceSearch(vi.L2Space(dim), n); bf.add_items(base); print(f"brute-force host copy {time.time() - t0:.0f}s", flush=True)
+bf.to_device(0); print(f"brute-force upload + prepare {time.time() - t0:.0f}s", flush=True)
+_, truth = bf.search_batch(dq[:nt], k); torch.cuda.synchronize(); truth = truth.cpu().numpy().view(np.uint64)
+del bf; torch.cuda.empty_cache()
+print(f"exact top-{k} of {nt} queries over {n} rows: {time.time() - t0:.0f}s in all", flush=True)
+
+import threading
+h = vi.HierarchicalNSW(vi.L2Space(dim), n, 16, 200, 100)
+t0 = time.time()
+building = threading.Event()
+def heartbeat():  # the C call is silent for minutes; the GPU box takes 3 silent minutes for a hang
+    while not building.wait(30):
+        print(f"  building ... {time.time() - t0:.0f}s", flush=True)
+hb = threading.Thread(target=heartbeat, daemon=True); hb.start()
+h.add_items_device(base, n_threads=16)
+building.set()
+build_s = time.time() - t0
+print(f"graph built on the device in {build_s:.0f}s ({n / build_s:.0f} points/s), max_level {h.max_level}, device image {h.device_bytes() / 1e9:.1f} GB", flush=True)
+out = {"config": f"C5: {n}x{dim}, L2, M=16, efC=200, {nq}-query batches, k={k}", "build_seconds_device": round(build_s), "device_gb": round(h.device_bytes() / 1e9, 1), "ef": {}}
+for ef in (100, 128, 200):
+    h.setefSearch(ef)
+    d, l, st = h.search_batch(dq, k, stats=True); torch.cuda.synchronize()
+    rec = datasets.recall_at_k(l[:nt].cpu().numpy().view(np.uint64), truth)
+    st = st.cpu().numpy().view(np.uint32).astype(np.int64)
+    alg = int((st[:, 0] * 512 + st[:, 1] * 132 + st[:, 2] * 68).sum() + nq * (512 + k * 12))
+    for _ in range(2): h.search_batch(dq, k)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    for a, b in ev:
+        a.record(); h.search_batch(dq, k); b.record()
+    torch.cuda.synchronize()
+    ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+    out["ef"][ef] = {"recall_at_100": round(rec, 4), "ms_per_batch": round(ms, 3), "queries_per_s": round(nq / ms * 1e3), "algorithmic_GBps": round(alg / ms / 1e6), "mean_ndis": round(float(st[:, 0].mean())), "mean_hops": round(float(st[:, 1].mean()), 1)}
+    print(f"ef={ef}: recall@{k} {rec:.4f}, {ms:.2f} ms per batch ({nq / ms * 1e3:.3e} q/s, {alg / ms / 1e6:.0f} GB/s algorithmic), ndis {st[:, 0].mean():.0f}, hops {st[:, 1].mean():.1f}", flush=True)
+print(json.dumps(out))
