@@ -5,6 +5,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -561,7 +564,17 @@ int vdb_index_add_batch_device(vdb_index* idx, const float* vecs, const uint64_t
         if (h.deleted != 0) throw Unsupported("device graph build with deleted elements in the index");
         if (h.ef_construction > kMaxEf) throw Unsupported("device graph build needs ef_construction <= 256");
         if (round_up(h.maxM0, 32) > kMaxL0Stride) throw Unsupported("M above 32 is not supported by the device path");
+        // VDB_TRACE=1: stage timings on stderr (a 100M-element build runs for minutes)
+        const bool trace = std::getenv("VDB_TRACE") != nullptr;
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!trace) return;
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[vdb build] %s: %.1fs\n", what, std::chrono::duration<double>(now - t_last).count());
+            t_last = now;
+        };
         const size_t base = h.append_unlinked(vecs, labels, n);
+        lap("rows stored");
         // host part: all elements with upper levels (their layer-0 links included), and enough level-0
         // ones for the graph to hold kSeed linked elements before the first device round
         const size_t kSeed = 2048;
@@ -580,9 +593,11 @@ int vdb_index_add_batch_device(vdb_index* idx, const float* vecs, const uint64_t
             }
         }
         h.link_elements(host_ids.data(), host_ids.size(), n_threads);
+        lap("host-linked elements (upper levels + seed)");
         if (dev_ids.empty()) return (int)VDB_OK;
 
         upload(idx, device);  // vectors of all elements, the links made so far, the finished upper layers
+        lap("upload");
         DeviceGuard guard(device);
         const DevGraph& g0 = idx->graph;
         const uint32_t efc = (uint32_t)h.ef_construction, M = (uint32_t)h.M, maxM0 = (uint32_t)h.maxM0;
@@ -645,6 +660,7 @@ int vdb_index_add_batch_device(vdb_index* idx, const float* vecs, const uint64_t
             linked += nb;
         }
         VDB_HIP(hipStreamSynchronize(stream));
+        lap("device rounds");
         // the device lists are the graph now: write them back in the reference's layout (:259-261, :283-285)
         const uint32_t ls = g0.l0stride;
         const size_t chunk = 1 << 16;
@@ -664,6 +680,7 @@ int vdb_index_add_batch_device(vdb_index* idx, const float* vecs, const uint64_t
                 std::memcpy(list + 1, r, (size_t)c * 4);
             }
         }
+        lap("write-back");
         h.version += 1;
         idx->device_version = h.version;  // the device copy IS this graph
         return (int)VDB_OK;
