@@ -26,8 +26,13 @@ def _recall(h, x, q, k, ef, labels=None):
     return datasets.recall_at_k(l, truth)
 
 
-@pytest.mark.parametrize("n,dim,metric,M,efc", [(30000, 32, vi.L2, 16, 200), (20000, 96, vi.IP, 8, 64), (3000, 16, vi.L2, 4, 32)])
-def test_device_build_recall_and_integrity(orc, tmp_path, n, dim, metric, M, efc):
+# host_base: sub-graphs up to this size are linked by the host builder; 64 forces the recursion over
+# the layers (layer l = layer 0 of an index over the elements of level >= l) down to a handful of elements
+@pytest.mark.parametrize("n,dim,metric,M,efc,host_base", [(30000, 32, vi.L2, 16, 200, 8192), (30000, 32, vi.L2, 16, 200, 64),
+                                                          (20000, 96, vi.IP, 8, 64, 64), (3000, 16, vi.L2, 4, 32, 64),
+                                                          (3000, 16, vi.L2, 4, 32, 8192)])
+def test_device_build_recall_and_integrity(orc, tmp_path, monkeypatch, n, dim, metric, M, efc, host_base):
+    monkeypatch.setenv("VDB_BUILD_HOST_BASE", str(host_base))
     x = datasets.clustered(n, dim, 71, normalize=(metric == vi.IP))
     q = datasets.clustered(500, dim, 72, normalize=(metric == vi.IP))
     labels = np.arange(n, dtype=np.uint64) + 10_000
@@ -43,6 +48,7 @@ def test_device_build_recall_and_integrity(orc, tmp_path, n, dim, metric, M, efc
     assert dev.getElementCount() == n
     # same level draw as the host builder: same level of every element, same upper-layer population
     assert [dev.level_of(i) for i in range(0, n, 97)] == [host.level_of(i) for i in range(0, n, 97)]
+    assert dev.max_level == host.max_level and dev.level_of(dev.entry) == dev.max_level
     rc, mn, mx = dev.checkIntegrity()
     assert rc in (0, 4), rc          # 4 = some node without inbound link: legal after pruning (as on the host build)
     r_dev = _recall(dev, x, q, 10, 64, labels)

@@ -553,9 +553,187 @@ int vdb_index_add_batch(vdb_index* idx, const float* vecs, const uint64_t* label
     });
 }
 
-// addPoint for a batch with layer 0 built on the device (hnsw_build.hip).  The host (reference
-// algorithm) inserts every element that has upper levels plus a seed of the graph; the rest go in
-// rounds of search -> select -> reverse links on the GPU.
+}  // extern "C"
+
+namespace {
+
+struct BuildTrace {  // VDB_TRACE=1: stage timings on stderr (a 100M-element build runs for minutes)
+    bool on = std::getenv("VDB_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void lap(const char* what, size_t n) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[vdb build] %-44s %9zu elements  %.1fs\n", what, n, std::chrono::duration<double>(now - last).count());
+        last = now;
+    }
+};
+
+// Upload, then insert `dev_ids` (stored, unlinked, level 0) into layer 0 in rounds of
+// search -> select -> sort -> reverse links (hnsw_build.hip), then write the lists back to the host.
+// `linked` = elements layer 0 already holds.
+void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t linked, int device, BuildTrace& tr) {
+    HostIndex& h = *idx->host;
+    upload(idx, device);  // vectors of all elements, the links made so far, the finished upper layers
+    tr.lap("upload", h.count);
+    DeviceGuard guard(device);
+    const DevGraph& g0 = idx->graph;
+    const uint32_t efc = (uint32_t)h.ef_construction, M = (uint32_t)h.M, maxM0 = (uint32_t)h.maxM0;
+    const size_t total = h.count;
+    const uint32_t max_batch = 32768;
+    DevBuf ident, ids, q, cd, cl, k_in, k_out, v_in, v_out, temp;
+    {
+        std::vector<uint64_t> id64(total);
+        for (size_t i = 0; i < total; ++i) id64[i] = i;
+        ident.alloc(total * 8);
+        VDB_HIP(hipMemcpy(ident.p, id64.data(), total * 8, hipMemcpyHostToDevice));
+    }
+    ids.alloc(dev_ids.size() * 4);
+    VDB_HIP(hipMemcpy(ids.p, dev_ids.data(), dev_ids.size() * 4, hipMemcpyHostToDevice));
+    q.alloc((size_t)max_batch * h.dim * 4);
+    cd.alloc((size_t)max_batch * efc * 4);
+    cl.alloc((size_t)max_batch * efc * 8);
+    BuildWork w;
+    const size_t pair_bytes = (size_t)max_batch * M * 4;
+    k_in.alloc(pair_bytes);
+    k_out.alloc(pair_bytes);
+    v_in.alloc(pair_bytes);
+    v_out.alloc(pair_bytes);
+    w.key_in = (uint32_t*)k_in.p;
+    w.key_out = (uint32_t*)k_out.p;
+    w.val_in = (uint32_t*)v_in.p;
+    w.val_out = (uint32_t*)v_out.p;
+    w.sort_temp_bytes = build_sort_temp_bytes(max_batch * M);
+    temp.alloc(w.sort_temp_bytes);
+    w.sort_temp = temp.p;
+
+    DevGraph gb = g0;  // the search returns internal ids
+    gb.labels = (const uint64_t*)ident.p;
+    uint32_t* links0 = (uint32_t*)idx->links0.p;
+    hipStream_t stream = nullptr;
+    SearchScratch* sc;
+    {
+        std::unique_lock<std::mutex> lock(idx->scratch_lock);
+        sc = &scratch_for(idx, stream, max_batch);
+    }
+    HnswSearchWork work;
+    work.redo = (uint32_t*)sc->redo.p;
+    work.bitmaps = (uint32_t*)sc->bitmaps.p;
+    work.bitmap_words = sc->bitmap_words;
+    std::string err;
+    size_t done = 0;
+    while (done < dev_ids.size()) {
+        // a batch is searched against the graph WITHOUT its own members: keep it a fraction of it
+        const size_t nb = std::min<size_t>(std::min<size_t>(max_batch, std::max<size_t>(linked / 4, 8)), dev_ids.size() - done);
+        const uint32_t* bid = (const uint32_t*)ids.p + done;
+        if (launch_gather_rows(g0.vecs, g0.vstride, g0.dim, bid, (uint32_t)nb, (float*)q.p, stream) != 0)
+            throw DeviceError("gather kernel launch failed");
+        int rc = launch_hnsw_search(gb, (const float*)q.p, (uint32_t)nb, efc, efc, nullptr, (float*)cd.p, (uint64_t*)cl.p, nullptr,
+                                    work, stream, &err);
+        if (rc == 0)
+            rc = launch_build_round(gb, links0, (const uint64_t*)cl.p, (const float*)cd.p, bid, (uint32_t)nb, efc, M, maxM0, w,
+                                    stream, &err);
+        if (rc != 0) throw DeviceError(err);
+        done += nb;
+        linked += nb;
+    }
+    VDB_HIP(hipStreamSynchronize(stream));
+    tr.lap("device rounds (layer 0)", dev_ids.size());
+    // the device lists are the graph now: write them back in the reference's layout (:259-261, :283-285)
+    const uint32_t ls = g0.l0stride;
+    const size_t chunk = 1 << 16;
+    std::vector<uint32_t> rows(chunk * ls);
+    for (size_t lo = 0; lo < total; lo += chunk) {
+        const size_t m = std::min(chunk, total - lo);
+        VDB_HIP(hipMemcpy(rows.data(), links0 + lo * ls, m * ls * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < m; ++i) {
+            uint32_t* list = h.list0((uint32_t)(lo + i));
+            const uint32_t* r = rows.data() + i * ls;
+            unsigned c = 0;
+            while (c < maxM0 && r[c] != kNoId) ++c;
+            const unsigned char flags = ((const unsigned char*)list)[2];
+            std::memset(list, 0, h.link0_stride);
+            HostIndex::set_list_count(list, c);
+            ((unsigned char*)list)[2] = flags;
+            std::memcpy(list + 1, r, (size_t)c * 4);
+        }
+    }
+    h.version += 1;
+    idx->device_version = h.version;  // the device copy IS this graph
+    tr.lap("write-back", total);
+}
+
+// Links every element of an index whose rows are stored and whose graph is EMPTY.
+//
+// Layer l >= 1 of an HNSW index is itself the layer 0 of an HNSW over the elements of level >= l
+// (same vectors, lists of capacity maxM instead of maxM0, levels one lower).  So: build that smaller
+// index first (recursively; small ones by the host builder, the reference algorithm), copy its lists
+// in as the upper layers, seed layer 0 of the elements with upper levels with their layer-1 lists
+// (a connected graph over them), and insert everything else into layer 0 by the device rounds; the
+// reverse links of those rounds fill and re-prune the seeded lists like any other.
+void build_empty_graph(vdb_index* idx, int n_threads, int device, size_t host_base, BuildTrace& tr) {
+    HostIndex& h = *idx->host;
+    const size_t n = h.count;
+    if (n <= host_base) {
+        std::vector<uint32_t> all(n);
+        for (size_t i = 0; i < n; ++i) all[i] = (uint32_t)i;
+        h.link_elements(all.data(), n, n_threads);
+        tr.lap("host-built graph (reference algorithm)", n);
+        return;
+    }
+    std::vector<uint32_t> s1, dev_ids;
+    for (size_t i = 0; i < n; ++i) (h.levels[i] > 0 ? s1 : dev_ids).push_back((uint32_t)i);
+    if (s1.empty()) {  // (n > host_base makes this practically impossible) the first element anchors the graph
+        s1.push_back(dev_ids.front());
+        dev_ids.erase(dev_ids.begin());
+    }
+    {
+        vdb_index sub;
+        sub.host.reset(new HostIndex(h.metric, h.dim, s1.size(), h.M, h.ef_construction, 100, /*layer0_lists_as_upper=*/true));
+        HostIndex& hs = *sub.host;
+        hs.set_sum_order(h.sum_order);
+        {
+            std::vector<float> v(std::min<size_t>(s1.size(), 1 << 16) * h.dim);
+            std::vector<int> lv(std::min<size_t>(s1.size(), 1 << 16));
+            for (size_t lo = 0; lo < s1.size(); lo += 1 << 16) {
+                const size_t m = std::min<size_t>(1 << 16, s1.size() - lo);
+                for (size_t i = 0; i < m; ++i) {
+                    std::memcpy(v.data() + i * h.dim, h.vec(s1[lo + i]), h.dim * 4);
+                    lv[i] = std::max(h.levels[s1[lo + i]] - 1, 0);
+                }
+                hs.append_unlinked(v.data(), nullptr, m, -1, lv.data());
+            }
+        }
+        build_empty_graph(&sub, n_threads, device, host_base, tr);
+        // its lists are this index's upper layers (and the seed of layer 0), ids mapped back
+        for (size_t j = 0; j < s1.size(); ++j) {
+            const uint32_t gid = s1[j];
+            h.alloc_upper_lists(gid);
+            for (int l = 0; l <= hs.levels[j]; ++l) {
+                const uint32_t* src = hs.list_at((uint32_t)j, l);
+                const unsigned c = HostIndex::list_count(src);
+                if (l + 1 <= h.levels[gid]) {
+                    uint32_t* dst = h.list_at(gid, l + 1);
+                    HostIndex::set_list_count(dst, c);
+                    for (unsigned i = 0; i < c; ++i) dst[1 + i] = s1[src[1 + i]];
+                }
+                if (l == 0) {
+                    uint32_t* dst = h.list0(gid);
+                    HostIndex::set_list_count(dst, c);
+                    for (unsigned i = 0; i < c; ++i) dst[1 + i] = s1[src[1 + i]];
+                }
+            }
+        }
+        h.set_entry(s1[hs.entry], hs.max_level + 1);
+        tr.lap("upper layers taken from the sub-index", s1.size());
+    }  // the sub-index and its device copy go away here
+    device_rounds(idx, dev_ids, s1.size(), device, tr);
+}
+
+}  // namespace
+
+extern "C" {
+
+// addPoint for a batch with the graph built on the device (hnsw_build.hip).
 int vdb_index_add_batch_device(vdb_index* idx, const float* vecs, const uint64_t* labels, size_t n, int n_threads, int device) {
     return guarded([&] {
         if (!idx || (!vecs && n)) throw std::invalid_argument("null argument");
@@ -564,125 +742,31 @@ int vdb_index_add_batch_device(vdb_index* idx, const float* vecs, const uint64_t
         if (h.deleted != 0) throw Unsupported("device graph build with deleted elements in the index");
         if (h.ef_construction > kMaxEf) throw Unsupported("device graph build needs ef_construction <= 256");
         if (round_up(h.maxM0, 32) > kMaxL0Stride) throw Unsupported("M above 32 is not supported by the device path");
-        // VDB_TRACE=1: stage timings on stderr (a 100M-element build runs for minutes)
-        const bool trace = std::getenv("VDB_TRACE") != nullptr;
-        auto t_last = std::chrono::steady_clock::now();
-        auto lap = [&](const char* what) {
-            if (!trace) return;
-            const auto now = std::chrono::steady_clock::now();
-            std::fprintf(stderr, "[vdb build] %s: %.1fs\n", what, std::chrono::duration<double>(now - t_last).count());
-            t_last = now;
-        };
+        BuildTrace tr;
         const size_t base = h.append_unlinked(vecs, labels, n);
-        lap("rows stored");
-        // host part: all elements with upper levels (their layer-0 links included), and enough level-0
-        // ones for the graph to hold kSeed linked elements before the first device round
-        const size_t kSeed = 2048;
+        tr.lap("rows stored", n);
+        // A new graph: every layer through the device rounds (small sub-graphs on the host).  Not for
+        // M < 8: there a quarter or more of the elements have upper levels, and their layer-0 lists,
+        // seeded from layer 1 and filled by reverse links only, cost recall (0.935 against 0.981 for
+        // the host build at M = 4) - those go the way of an append below.
+        if (base == 0 && h.M >= 8) {
+            size_t host_base = 8192;
+            if (const char* e = std::getenv("VDB_BUILD_HOST_BASE")) host_base = (size_t)std::max(64l, std::atol(e));
+            build_empty_graph(idx, n_threads, device, host_base, tr);
+            if (idx->device < 0 || idx->device_version != h.version) upload(idx, device);
+            return (int)VDB_OK;
+        }
+        // appending to an existing graph: the host builder (reference algorithm) inserts the elements
+        // that have upper levels, the others go into layer 0 by the device rounds
         std::vector<uint32_t> host_ids, dev_ids;
-        size_t linked = base;
-        for (size_t i = 0; i < n; ++i)
-            if (h.levels[base + i] > 0) host_ids.push_back((uint32_t)(base + i));
-        linked += host_ids.size();
-        for (size_t i = 0; i < n; ++i) {
-            if (h.levels[base + i] > 0) continue;
-            if (linked < kSeed) {
-                host_ids.push_back((uint32_t)(base + i));
-                linked += 1;
-            } else {
-                dev_ids.push_back((uint32_t)(base + i));
-            }
-        }
+        for (size_t i = 0; i < n; ++i) (h.levels[base + i] > 0 ? host_ids : dev_ids).push_back((uint32_t)(base + i));
         h.link_elements(host_ids.data(), host_ids.size(), n_threads);
-        lap("host-linked elements (upper levels + seed)");
-        if (dev_ids.empty()) return (int)VDB_OK;
-
-        upload(idx, device);  // vectors of all elements, the links made so far, the finished upper layers
-        lap("upload");
-        DeviceGuard guard(device);
-        const DevGraph& g0 = idx->graph;
-        const uint32_t efc = (uint32_t)h.ef_construction, M = (uint32_t)h.M, maxM0 = (uint32_t)h.maxM0;
-        const size_t total = h.count;
-        const uint32_t max_batch = 32768;
-        DevBuf ident, ids, q, cd, cl, k_in, k_out, v_in, v_out, temp;
-        {
-            std::vector<uint64_t> id64(total);
-            for (size_t i = 0; i < total; ++i) id64[i] = i;
-            ident.alloc(total * 8);
-            VDB_HIP(hipMemcpy(ident.p, id64.data(), total * 8, hipMemcpyHostToDevice));
+        tr.lap("host-linked elements with upper levels", host_ids.size());
+        if (dev_ids.empty()) {
+            upload(idx, device);
+            return (int)VDB_OK;
         }
-        ids.alloc(dev_ids.size() * 4);
-        VDB_HIP(hipMemcpy(ids.p, dev_ids.data(), dev_ids.size() * 4, hipMemcpyHostToDevice));
-        q.alloc((size_t)max_batch * h.dim * 4);
-        cd.alloc((size_t)max_batch * efc * 4);
-        cl.alloc((size_t)max_batch * efc * 8);
-        BuildWork w;
-        const size_t pair_bytes = (size_t)max_batch * M * 4;
-        k_in.alloc(pair_bytes);
-        k_out.alloc(pair_bytes);
-        v_in.alloc(pair_bytes);
-        v_out.alloc(pair_bytes);
-        w.key_in = (uint32_t*)k_in.p;
-        w.key_out = (uint32_t*)k_out.p;
-        w.val_in = (uint32_t*)v_in.p;
-        w.val_out = (uint32_t*)v_out.p;
-        w.sort_temp_bytes = build_sort_temp_bytes(max_batch * M);
-        temp.alloc(w.sort_temp_bytes);
-        w.sort_temp = temp.p;
-
-        DevGraph gb = g0;  // the search returns internal ids
-        gb.labels = (const uint64_t*)ident.p;
-        uint32_t* links0 = (uint32_t*)idx->links0.p;
-        hipStream_t stream = nullptr;
-        SearchScratch* sc;
-        {
-            std::unique_lock<std::mutex> lock(idx->scratch_lock);
-            sc = &scratch_for(idx, stream, max_batch);
-        }
-        HnswSearchWork work;
-        work.redo = (uint32_t*)sc->redo.p;
-        work.bitmaps = (uint32_t*)sc->bitmaps.p;
-        work.bitmap_words = sc->bitmap_words;
-        std::string err;
-        size_t done = 0;
-        while (done < dev_ids.size()) {
-            // a batch is searched against the graph WITHOUT its own members: keep it a fraction of it
-            size_t nb = std::min<size_t>(std::min<size_t>(max_batch, std::max<size_t>(linked / 4, 64)), dev_ids.size() - done);
-            const uint32_t* bid = (const uint32_t*)ids.p + done;
-            if (launch_gather_rows(g0.vecs, g0.vstride, g0.dim, bid, (uint32_t)nb, (float*)q.p, stream) != 0)
-                throw DeviceError("gather kernel launch failed");
-            int rc = launch_hnsw_search(gb, (const float*)q.p, (uint32_t)nb, efc, efc, nullptr, (float*)cd.p, (uint64_t*)cl.p,
-                                        nullptr, work, stream, &err);
-            if (rc == 0)
-                rc = launch_build_round(gb, links0, (const uint64_t*)cl.p, (const float*)cd.p, bid, (uint32_t)nb, efc, M, maxM0, w,
-                                        stream, &err);
-            if (rc != 0) return set_error(rc, err);
-            done += nb;
-            linked += nb;
-        }
-        VDB_HIP(hipStreamSynchronize(stream));
-        lap("device rounds");
-        // the device lists are the graph now: write them back in the reference's layout (:259-261, :283-285)
-        const uint32_t ls = g0.l0stride;
-        const size_t chunk = 1 << 16;
-        std::vector<uint32_t> rows(chunk * ls);
-        for (size_t lo = 0; lo < total; lo += chunk) {
-            const size_t m = std::min(chunk, total - lo);
-            VDB_HIP(hipMemcpy(rows.data(), links0 + lo * ls, m * ls * 4, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < m; ++i) {
-                uint32_t* list = h.list0((uint32_t)(lo + i));
-                const uint32_t* r = rows.data() + i * ls;
-                unsigned c = 0;
-                while (c < maxM0 && r[c] != kNoId) ++c;
-                const unsigned char flags = ((const unsigned char*)list)[2];
-                std::memset(list, 0, h.link0_stride);
-                HostIndex::set_list_count(list, c);
-                ((unsigned char*)list)[2] = flags;
-                std::memcpy(list + 1, r, (size_t)c * 4);
-            }
-        }
-        lap("write-back");
-        h.version += 1;
-        idx->device_version = h.version;  // the device copy IS this graph
+        device_rounds(idx, dev_ids, base + host_ids.size(), device, tr);
         return (int)VDB_OK;
     });
 }

@@ -43,7 +43,7 @@ double HostIndex::LevelRng::uniform() {
 
 void HostIndex::init_layout() {  // :140-152, :176-178
     maxM = M;
-    maxM0 = 2 * M;
+    maxM0 = layer0_as_upper_ ? M : 2 * M;
     data_size = dim * sizeof(float);
     link0_stride = maxM0 * sizeof(uint32_t) + sizeof(uint32_t);
     stride = link0_stride + data_size + sizeof(uint64_t);
@@ -69,7 +69,8 @@ void HostIndex::alloc_storage(size_t cap) {
     capacity = cap;
 }
 
-HostIndex::HostIndex(int metric_, size_t dim_, size_t cap, size_t M_, size_t efc, size_t seed) {
+HostIndex::HostIndex(int metric_, size_t dim_, size_t cap, size_t M_, size_t efc, size_t seed, bool layer0_lists_as_upper) {
+    layer0_as_upper_ = layer0_lists_as_upper;
     if (dim_ == 0) throw std::invalid_argument("dim must be > 0");
     if (M_ < 2) throw std::invalid_argument("M must be >= 2");
     metric = metric_;
@@ -323,7 +324,7 @@ void HostIndex::add(const float* v, uint64_t label, int level) {
 
 // Ids, levels and rows of n new elements, assigned in input order exactly as n sequential addPoint
 // calls would (:1018-1043); nothing is linked yet.  Returns the first new id.
-size_t HostIndex::append_unlinked(const float* vecs, const uint64_t* labels, size_t n, int forced_level) {
+size_t HostIndex::append_unlinked(const float* vecs, const uint64_t* labels, size_t n, int forced_level, const int* given_levels) {
     const size_t base = count;
     if (base + n > capacity) throw std::runtime_error("The number of elements exceeds the specified limit");  // :1018-1020
     {
@@ -339,6 +340,7 @@ size_t HostIndex::append_unlinked(const float* vecs, const uint64_t* labels, siz
     for (size_t i = 0; i < n; ++i) {
         int lv = draw_level();  // drawn even when overridden, as :1028-1029
         if (forced_level > 0) lv = forced_level;
+        if (given_levels) lv = given_levels[i];
         const uint32_t id = (uint32_t)(base + i);
         char* r = row(id);
         std::memset(r, 0, stride);  // :1039
@@ -350,6 +352,13 @@ size_t HostIndex::append_unlinked(const float* vecs, const uint64_t* labels, siz
     count = base + n;
     ++version;
     return base;
+}
+
+void HostIndex::alloc_upper_lists(uint32_t id) {
+    if (levels[id] <= 0) return;
+    if (upper[id]) throw std::runtime_error("element already has upper-layer lists");
+    upper[id] = (char*)std::calloc(link_stride * (size_t)levels[id] + 1, 1);  // :1046-1049
+    if (!upper[id]) throw std::runtime_error("Not enough memory: addPoint failed to allocate linklist");
 }
 
 // addPoint's linking (:1044-1103) for elements that append_unlinked stored, in the order given.

@@ -73,7 +73,9 @@ public:
     int sum_order = 1;  // vdb_sum_order
     uint64_t version = 0;  // bumped by every mutation; the device copy remembers the one it mirrors
 
-    HostIndex(int metric, size_t dim, size_t capacity, size_t M, size_t efc, size_t seed);
+    // layer0_lists_as_upper: layer 0 gets the capacity of an upper layer (maxM0 = M).  Only the device
+    // builder uses it, for the HNSW over the elements of level >= l that IS layer l of a larger index.
+    HostIndex(int metric, size_t dim, size_t capacity, size_t M, size_t efc, size_t seed, bool layer0_lists_as_upper = false);
     HostIndex(const std::string& path, int metric, size_t dim, size_t capacity_hint);
     ~HostIndex();
     HostIndex(const HostIndex&) = delete;
@@ -82,7 +84,15 @@ public:
     void add(const float* vec, uint64_t label, int level);
     void add_batch(const float* vecs, const uint64_t* labels, size_t n, int n_threads, int forced_level = -1);
     // the two halves of add_batch, for the device builder (hnsw_build.hip): store, then link a subset on the host
-    size_t append_unlinked(const float* vecs, const uint64_t* labels, size_t n, int forced_level = -1);
+    size_t append_unlinked(const float* vecs, const uint64_t* labels, size_t n, int forced_level = -1,
+                           const int* given_levels = nullptr);
+    // upper-layer lists of `id` (levels[id] of them), zeroed; the element must not have any yet
+    void alloc_upper_lists(uint32_t id);
+    void set_entry(uint32_t id, int level) {
+        entry = id;
+        max_level = level;
+        ++version;
+    }
     void link_elements(const uint32_t* ids, size_t n, int n_threads);
     void save(const std::string& path) const;
     void mark_delete(uint64_t label, bool undo);
@@ -118,6 +128,7 @@ private:
     std::unordered_map<uint64_t, uint32_t> label_map_;
     dist_fn dist_ = nullptr;
 
+    bool layer0_as_upper_ = false;
     void init_layout();
     void alloc_storage(size_t cap);
     void release();
