@@ -619,9 +619,25 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
     work.redo = (uint32_t*)sc->redo.p;
     work.bitmaps = (uint32_t*)sc->bitmaps.p;
     work.bitmap_words = sc->bitmap_words;
+    // the visited-set size follows what the rounds report, as in search_device: the searches of a
+    // large graph at ef_construction visit more nodes than the default table holds, and the large
+    // configuration (an n-bit map per re-run query) is no place for a whole batch
+    if (!sc->report) {
+        VDB_HIP(hipHostMalloc((void**)&sc->report, 8, hipHostMallocMapped));
+        sc->report[0] = sc->report[1] = 0;
+    }
+    sc->report_ef = 0;  // (not an observation of a query launch)
+    work.report = sc->report;
     std::string err;
-    size_t done = 0;
+    size_t done = 0, round = 0;
     while (done < dev_ids.size()) {
+        {
+            const uint32_t redone = ((volatile uint32_t*)sc->report)[0], of = ((volatile uint32_t*)sc->report)[1];
+            if (of != 0) {
+                if ((uint64_t)redone * 50u > of && work.hbits_bias < 3) work.hbits_bias += 1;
+                ((volatile uint32_t*)sc->report)[1] = 0;
+            }
+        }
         // a batch is searched against the graph WITHOUT its own members: keep it a fraction of it
         const size_t nb = std::min<size_t>(std::min<size_t>(max_batch, std::max<size_t>(linked / 4, 8)), dev_ids.size() - done);
         const uint32_t* bid = (const uint32_t*)ids.p + done;
@@ -635,8 +651,15 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
         if (rc != 0) throw DeviceError(err);
         done += nb;
         linked += nb;
+        if (tr.on && ++round % 256 == 0) {
+            VDB_HIP(hipStreamSynchronize(stream));
+            std::fprintf(stderr, "[vdb build]   round %zu: %zu of %zu elements, visited-set bias %u, %.1fs\n", round, done,
+                         dev_ids.size(), work.hbits_bias,
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - tr.last).count());
+        }
     }
     VDB_HIP(hipStreamSynchronize(stream));
+    sc->report[1] = 0;
     tr.lap("device rounds (layer 0)", dev_ids.size());
     // the device lists are the graph now: write them back in the reference's layout (:259-261, :283-285)
     const uint32_t ls = g0.l0stride;
