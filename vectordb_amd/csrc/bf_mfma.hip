@@ -36,6 +36,7 @@
 // one hot k-step).  Rows up to the next multiple of 256 exist and hold zeros.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <string>
 #include <type_traits>
@@ -120,28 +121,30 @@ __global__ __launch_bounds__(256) void bf_colsum_final(const double* partial, ui
 __global__ __launch_bounds__(256) void bf_center(const float* x, uint32_t n, uint32_t dim, uint32_t vstride, uint32_t kp64,
                                                  const float* mu, float* xc, __bf16* xb, float* nx, float* stats) {
     const int lane = threadIdx.x & 63;
-    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t npad = (n + 255u) & ~255u;
-    if (row >= npad) return;
-    const bool real = row < n;
     const uint32_t ksf = vstride >> 4, ksb = kp64 >> 5;
-    double s = 0.0;
-    for (uint32_t c = lane; c < kp64; c += 64) {
-        float v = 0.f;
-        if (real && c < dim) v = x[(size_t)row * vstride + c] - mu[c];
-        if (c < vstride) xc[panel_f32(row, c, ksf)] = v;
-        xb[panel_bf16(row, c, ksb)] = (__bf16)v;
-        s += (double)v * (double)v;
-    }
-    if (!real) return;
-    s = wave_sum(s);
-    if (lane == 0) {
-        nx[row] = (float)s;
-        const float norm = (float)__builtin_sqrt(s) * 1.0000002f;  // round up: it feeds an error BOUND
-        // one hot word for every row of the table: only rows that raise the maximum touch it
-        const uint32_t nb = __builtin_bit_cast(uint32_t, norm);
-        uint32_t* mx = reinterpret_cast<uint32_t*>(stats);
-        if (nb > __hip_atomic_load(mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(mx, nb);
+    // grid-stride over the rows: a launch cannot have 2^32 or more threads (the dispatch packet counts
+    // work-items in 32 bits), which one block of 256 per four rows reaches at 67M rows
+    for (uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6); row < npad; row += gridDim.x * 4) {
+        const bool real = row < n;
+        double s = 0.0;
+        for (uint32_t c = lane; c < kp64; c += 64) {
+            float v = 0.f;
+            if (real && c < dim) v = x[(size_t)row * vstride + c] - mu[c];
+            if (c < vstride) xc[panel_f32(row, c, ksf)] = v;
+            xb[panel_bf16(row, c, ksb)] = (__bf16)v;
+            s += (double)v * (double)v;
+        }
+        if (!real) continue;
+        s = wave_sum(s);
+        if (lane == 0) {
+            nx[row] = (float)s;
+            const float norm = (float)__builtin_sqrt(s) * 1.0000002f;  // round up: it feeds an error BOUND
+            // one hot word for every row of the table: only rows that raise the maximum touch it
+            const uint32_t nb = __builtin_bit_cast(uint32_t, norm);
+            uint32_t* mx = reinterpret_cast<uint32_t*>(stats);
+            if (nb > __hip_atomic_load(mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(mx, nb);
+        }
     }
 }
 
@@ -595,7 +598,7 @@ int launch_bf_prepare(const float* d_raw, uint32_t n, uint32_t dim, uint32_t vst
     hipLaunchKernelGGL(bf_colsum_partial, dim3(kSumBlocks), dim3(256), 0, stream, d_raw, n, vstride, partial);
     hipLaunchKernelGGL(bf_colsum_final, dim3(1), dim3(256), 0, stream, partial, n, vstride, d_mu, d_stats);
     if (n)
-        hipLaunchKernelGGL(bf_center, dim3((((n + 255u) & ~255u) + 3) / 4), dim3(256), 0, stream, d_raw, n, dim, vstride, kp64, d_mu, d_xc,
+        hipLaunchKernelGGL(bf_center, dim3(std::min<uint32_t>((((n + 255u) & ~255u) + 3) / 4, 1u << 20)), dim3(256), 0, stream, d_raw, n, dim, vstride, kp64, d_mu, d_xc,
                            static_cast<__bf16*>(d_xb), d_nx, d_stats);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
