@@ -106,3 +106,21 @@ def test_bruteforce_host_semantics(orc, tmp_path):
     assert b2.getElementCount() == 9
     with pytest.raises(vi.VdbError, match="exceeds"):
         b2.add_items(rand(20, 6, 5), np.arange(1000, 1020, dtype=np.uint64))
+
+
+def test_device_build_refuses_before_it_stores_anything():
+    """vdb_index_add_batch_device: unsupported parameters and a missing device are reported before the
+    index is touched (there is no CPU fallback for the device builder)."""
+    from vectordb_amd import _lib
+    x = np.random.default_rng(0).random((100, 8), dtype=np.float32)
+    h = vi.HierarchicalNSW(vi.L2Space(8), 100, 16, 300, 100)      # ef_construction above the device limit
+    with pytest.raises(vi.VdbError) as e:
+        h.add_items_device(x)
+    assert e.value.code == _lib.VDB_ERR_UNSUPPORTED and h.getElementCount() == 0
+    if _lib.lib().vdb_device_count() == 0:
+        h = vi.HierarchicalNSW(vi.L2Space(8), 100, 16, 200, 100)
+        with pytest.raises(vi.VdbError) as e:
+            h.add_items_device(x)
+        assert e.value.code == _lib.VDB_ERR_NO_DEVICE and h.getElementCount() == 0
+        h.add_items(x)                                            # the host builder still works on it
+        assert h.getElementCount() == 100

@@ -765,6 +765,13 @@ int vdb_index_add_batch_device(vdb_index* idx, const float* vecs, const uint64_t
         if (h.deleted != 0) throw Unsupported("device graph build with deleted elements in the index");
         if (h.ef_construction > kMaxEf) throw Unsupported("device graph build needs ef_construction <= 256");
         if (round_up(h.maxM0, 32) > kMaxL0Stride) throw Unsupported("M above 32 is not supported by the device path");
+        if (round_up(h.dim, 32) > kMaxVecStride) throw Unsupported("dim above 1024 is not supported by the device path");
+        {  // nothing is stored unless the device is there: a failed call leaves the index as it was
+            int ndev = 0;
+            if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw DeviceError("no HIP device visible");
+            if (device < 0 || device >= ndev) throw std::invalid_argument("device ordinal out of range");
+            if (h.count + n > h.capacity) throw std::runtime_error("The number of elements exceeds the specified limit");
+        }
         BuildTrace tr;
         const size_t base = h.append_unlinked(vecs, labels, n);
         tr.lap("rows stored", n);
