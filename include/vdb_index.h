@@ -85,7 +85,7 @@ int vdb_index_add_batch(vdb_index* idx, const float* vecs, const uint64_t* label
  * rounds of search (ef_construction) -> heuristic selection (:357-390) -> reverse links (:392-498) on
  * the GPU.  Levels, ids and labels are assigned exactly as vdb_index_add_batch does; the links are a
  * valid HNSW graph but not the sequential builder's graph (a batch has no insertion order).  Leaves
- * the index uploaded to `device`.  Needs ef_construction <= 256, M <= 32, no deleted elements. */
+ * the index uploaded to `device`.  Needs ef_construction <= 508, M <= 32, no deleted elements. */
 int vdb_index_add_batch_device(vdb_index* idx, const float* vecs, const uint64_t* labels, size_t n, int n_threads,
                                int device);
 /* Summation order used by host-side build distances (default VDB_SUM_TREE64). */

@@ -96,6 +96,29 @@ def test_visited_overflow_falls_back_exactly(orc):
     assert_same_results((dist, label), o.search(q, 100), st)
 
 
+@pytest.mark.parametrize("ef,k", [(300, 300), (316, 100), (317, 10), (508, 508), (124, 124), (125, 100), (60, 60), (61, 50)])
+def test_large_ef_and_key_array_boundaries(orc, ef, k):
+    """Every key-array size (1, 2, 4, 5, 8 registers per lane) at its boundary, k up to ef = 508."""
+    x = datasets.clustered(20000, 24, 13)
+    q = datasets.clustered(64, 24, 14)
+    h, o = build_pair(orc, x, vi.L2, 16, 100, n_threads=4)
+    h.to_device(0)
+    h.setefSearch(ef)
+    o.set_ef(ef)
+    dist, label, st = h.search_batch(q, k, stats=True)
+    assert_same_results((dist, label), o.search(q, k), st)
+
+
+def test_ef_above_the_device_limit_is_reported(orc):
+    x = datasets.uniform(500, 8, 15)
+    h, _ = build_pair(orc, x, vi.L2, 8, 32)
+    h.to_device(0)
+    h.setefSearch(509)
+    with pytest.raises(vi.VdbError) as e:
+        h.search_batch(x[:4], 5)
+    assert e.value.code == 4
+
+
 def test_device_pointer_api_and_errors(orc):
     import torch
     x = datasets.uniform(1000, 64, 1)
@@ -113,7 +136,7 @@ def test_device_pointer_api_and_errors(orc):
     ref = o.search(q, 10)
     np.testing.assert_array_equal(label.cpu().numpy().view(np.uint64), ref["label"].astype(np.uint64))
     np.testing.assert_array_equal(dist.cpu().numpy().view(np.uint32), ref["dist"].view(np.uint32))
-    h.setefSearch(300)
+    h.setefSearch(600)
     with pytest.raises(vi.VdbError) as e:
         h.search_batch(q, 10)
     assert e.value.code == 4

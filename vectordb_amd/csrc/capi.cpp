@@ -404,7 +404,7 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
     if (nq > 0x7FFFFFFFull || k > 0x7FFFFFFFull) throw std::invalid_argument("batch too large");
     DeviceGuard guard(idx->device);
     const size_t ef = std::max(idx->host->ef_search, k);  // hnsw_core.hpp:1144
-    if (ef > kMaxEf) throw Unsupported("max(efSearch, k) above 256 is not supported by the device path");
+    if (ef > kMaxEf) throw Unsupported("max(efSearch, k) above 508 is not supported by the device path");
     std::unique_lock<std::mutex> lock(idx->scratch_lock);
     SearchScratch& s = scratch_for(idx, stream, nq);
     // bare = no deleted element and no filter (hnsw_core.hpp:1141); else one bitmap of allowed nodes
@@ -763,7 +763,7 @@ int vdb_index_add_batch_device(vdb_index* idx, const float* vecs, const uint64_t
         if (n == 0) return (int)VDB_OK;
         HostIndex& h = *idx->host;
         if (h.deleted != 0) throw Unsupported("device graph build with deleted elements in the index");
-        if (h.ef_construction > kMaxEf) throw Unsupported("device graph build needs ef_construction <= 256");
+        if (h.ef_construction > kMaxEf) throw Unsupported("device graph build needs ef_construction <= 508");
         if (round_up(h.maxM0, 32) > kMaxL0Stride) throw Unsupported("M above 32 is not supported by the device path");
         if (round_up(h.dim, 32) > kMaxVecStride) throw Unsupported("dim above 1024 is not supported by the device path");
         {  // nothing is stored unless the device is there: a failed call leaves the index as it was

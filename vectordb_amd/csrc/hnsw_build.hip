@@ -226,7 +226,7 @@ int launch_build_round(const DevGraph& g, uint32_t* d_links0, const uint64_t* d_
                        hipStream_t stream, std::string* err) {
     if (nb == 0) return 0;
     if (efc > kMaxEf || M > 64 || g.l0stride > kMaxL0Stride || maxM0 > g.l0stride) {
-        if (err) *err = "device graph build: ef_construction above 256 or M above 32 is not supported";
+        if (err) *err = "device graph build: ef_construction above 508 or M above 32 is not supported";
         return 4;
     }
     const uint32_t n_pairs = nb * M;

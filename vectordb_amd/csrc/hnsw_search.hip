@@ -629,7 +629,8 @@ int launch_r(const SearchArgs& a, hipStream_t stream, std::string* err) {
     if (a.ef <= 60) return launch_cfg<NCH, GPB, 1, 2, false>(a, stream, err);
     if (a.ef <= 124) return launch_cfg<NCH, GPB, 2, 4, false>(a, stream, err);
     if (a.ef <= 252) return launch_cfg<NCH, GPB, 4, 8, false>(a, stream, err);
-    return launch_cfg<NCH, GPB, 5, 10, false>(a, stream, err);
+    if (a.ef <= 316) return launch_cfg<NCH, GPB, 5, 10, false>(a, stream, err);
+    return launch_cfg<NCH, GPB, 8, 16, false>(a, stream, err);
 }
 
 }  // namespace
@@ -648,7 +649,7 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
         if (err) *err = what;
         return 4;
     };
-    if (ef == 0 || ef > kMaxEf) return unsupported("ef (= max(efSearch, k)) above 256 is not supported by the device path");
+    if (ef == 0 || ef > kMaxEf) return unsupported("ef (= max(efSearch, k)) above 508 is not supported by the device path");
     if (g.vstride > kMaxVecStride) return unsupported("dim above 1024 is not supported by the device path");
     if (g.l0stride > kMaxL0Stride || g.ustride > kMaxL0Stride) return unsupported("M above 32 is not supported by the device path");
     if (d_allow && g.n >= (1u << 30)) return unsupported("filtered search needs fewer than 2^30 elements per index (shard it)");

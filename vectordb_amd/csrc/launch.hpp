@@ -10,7 +10,7 @@
 namespace vdb {
 
 // Limits of the traversal kernels (checked by the launcher, reported as VDB_ERR_UNSUPPORTED).
-constexpr uint32_t kMaxEf = 256;           // sorted key array: 4 registers per lane, 8 in the large configuration
+constexpr uint32_t kMaxEf = 508;           // sorted key array: up to 8 registers per lane (512 keys), 16 in the large configuration
 constexpr uint32_t kMaxVecStride = 1024;   // floats per row (16 chunks of 64)
 constexpr uint32_t kMaxL0Stride = 64;      // layer-0 list slots (maxM0 <= 64, i.e. M <= 32)
 constexpr uint32_t kLargeBlocks = 128;     // resident waves of the large configuration (one bitmap each)
