@@ -58,6 +58,9 @@ def main() -> None:
                     help="hnsw = BASELINE.json configs[1] (the headline metric); bruteforce = configs[2] "
                          "(exact k-NN 1M x 960 on the MFMA path, its own JSON line)")
     ap.add_argument("--precision", choices=("fp32", "bf16", "bf16_rerank"), default="bf16_rerank")
+    ap.add_argument("--build", choices=("host", "device"), default="host",
+                    help="graph builder: host = the reference algorithm on the host cores (default: the graph the headline\n"
+                         "number is quoted on), device = vdb_index_add_batch_device (DESIGN.md 4.3)")
     args = ap.parse_args()
     if args.workload == "bruteforce":
         return run_bruteforce(args)
@@ -104,12 +107,15 @@ def main() -> None:
     # ---- graph build on the host cores (reference algorithm), upload ------------------
     t0 = time.time()
     h = vi.HierarchicalNSW(vi.L2Space(args.dim), args.n, args.M, args.efc, 100)
-    h.add_items(base, n_threads=threads)
+    if args.build == "device":
+        h.add_items_device(base, n_threads=threads, device=local_rank)
+    else:
+        h.add_items(base, n_threads=threads)
     build_s = time.time() - t0
     t0 = time.time()
     h.to_device(local_rank)
     if rank == 0:
-        log(f"graph built in {build_s:.1f}s on {threads} threads, uploaded {h.device_bytes() / 1e6:.0f} MB in "
+        log(f"graph built in {build_s:.1f}s ({args.build} builder, {threads} host threads), uploaded {h.device_bytes() / 1e6:.0f} MB in "
             f"{time.time() - t0:.1f}s, max_level {h.max_level}")
 
     dq = torch.from_numpy(queries).to(dev)
@@ -260,7 +266,8 @@ def main() -> None:
                        "ef": chosen, "recall_at_10": round(recall, 4), "ef_sweep": sweep,
                        "parallelism": "query-parallel replicas" if world > 1 else "single GPU",
                        "mean_ndis": round(float(st[:, 0].mean()), 1), "mean_hops": round(float(st[:, 1].mean()), 1),
-                       "build_seconds_host": round(build_s, 1), "build_threads": threads},
+                       "build_seconds_host" if args.build == "host" else "build_seconds_device": round(build_s, 1),
+                       "build_threads": threads},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src, "kernel": "hnsw_search_kernel", "kernel_ms": round(kern_ms, 4),
