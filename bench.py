@@ -243,7 +243,7 @@ def main() -> None:
         # when the workload is the one it was collected on.
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r1", "hnsw_c2_pmc_fetch_tuned.json")
-        if os.path.exists(pmc) and (args.n, args.dim, args.nq, args.k, args.M, chosen) == (1_000_000, 128, 10_000, 10, 16, 32):
+        if os.path.exists(pmc) and args.build == "host" and (args.n, args.dim, args.nq, args.k, args.M, chosen) == (1_000_000, 128, 10_000, 10, 16, 32):
             with open(pmc) as f:
                 traffic = int(json.load(f)["traffic_bytes_per_launch"])
             traffic_src = "profiles/r1/hnsw_c2_pmc_fetch_tuned.json (FETCH_SIZE KB x 1024 x 2, gfx950 correction)"
