@@ -242,11 +242,11 @@ def main() -> None:
         # command (counters cannot be read from inside the process); the committed summary is quoted
         # when the workload is the one it was collected on.
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r1", "hnsw_c2_pmc_fetch_tuned.json")
+        pmc = os.path.join(ROOT, "profiles", "r1", "hnsw_c2_pmc_fetch_final.json")
         if os.path.exists(pmc) and args.build == "host" and (args.n, args.dim, args.nq, args.k, args.M, chosen) == (1_000_000, 128, 10_000, 10, 16, 32):
             with open(pmc) as f:
                 traffic = int(json.load(f)["traffic_bytes_per_launch"])
-            traffic_src = "profiles/r1/hnsw_c2_pmc_fetch_tuned.json (FETCH_SIZE KB x 1024 x 2, gfx950 correction)"
+            traffic_src = "profiles/r1/hnsw_c2_pmc_fetch_final.json (FETCH_SIZE KB x 1024 x 2, gfx950 correction)"
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "queries/sec @ recall@10>=0.95 (1M x 128, k=10)",
