@@ -40,7 +40,7 @@ building.set()
 build_s = time.time() - t0
 print(f"graph built on the device in {build_s:.0f}s ({n / build_s:.0f} points/s), max_level {h.max_level}, device image {h.device_bytes() / 1e9:.1f} GB", flush=True)
 out = {"config": f"C5: {n}x{dim}, L2, M=16, efC=200, {nq}-query batches, k={k}", "build_seconds_device": round(build_s), "device_gb": round(h.device_bytes() / 1e9, 1), "ef": {}}
-for ef in (100, 128, 200):
+for ef in [int(v) for v in os.environ.get("EXP_EFS", "100,128,200").split(",")]:
     h.setefSearch(ef)
     d, l, st = h.search_batch(dq, k, stats=True); torch.cuda.synchronize()
     rec = datasets.recall_at_k(l[:nt].cpu().numpy().view(np.uint64), truth)
