@@ -101,6 +101,7 @@ size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 // Per-stream scratch of the traversal (work list of re-run queries + visited bitmaps).
 struct SearchScratch {
     DevBuf redo, bitmaps, allow;  // allow: delete flags AND the caller's filter, when both exist
+    DevBuf ghash;                 // visited tables in HBM for the large-ef configuration (allocated on first need)
     // host-mapped {re-run queries, nq} written by the last launch on this stream, and the ef it ran at:
     // read (without synchronising) before the next launch to size the visited set (see search_device)
     uint32_t* report = nullptr;
@@ -443,6 +444,10 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
     work.redo = (uint32_t*)s.redo.p;
     work.bitmaps = (uint32_t*)s.bitmaps.p;
     work.bitmap_words = s.bitmap_words;
+    if (ef > 124 && !allow) {
+        if (!s.ghash.p) s.ghash.alloc(((size_t)kGlobalHashBlocks << kGlobalHashBits) * 4);
+        work.ghash = (uint32_t*)s.ghash.p;
+    }
     work.report = s.report;
     {
         auto it = idx->hbits_bias.find((uint32_t)ef);
@@ -627,6 +632,10 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
         sc->report[0] = sc->report[1] = 0;
     }
     sc->report_ef = 0;  // (not an observation of a query launch)
+    if (efc > 124) {
+        if (!sc->ghash.p) sc->ghash.alloc(((size_t)kGlobalHashBlocks << kGlobalHashBits) * 4);
+        work.ghash = (uint32_t*)sc->ghash.p;
+    }
     work.report = sc->report;
     std::string err;
     size_t done = 0, round = 0;

@@ -70,6 +70,31 @@ struct LdsVisited {
     __device__ __forceinline__ uint32_t limit() const { return (3u << hbits) >> 2; }  // 75 % fill
 };
 
+// The same hash in HBM, one table per resident wave: for searches that visit thousands of nodes (large
+// ef on large graphs, the builder at ef_construction), where an LDS table of 32-64 KB would leave two
+// to five queries resident per CU.  A probe costs an L2 round trip instead of an LDS one; residency is
+// then bounded by registers only.
+struct GlobalHashVisited {
+    uint32_t* tab;
+    uint32_t hbits;
+    __device__ __forceinline__ void clear(int lane) {
+        const uint32_t n = 1u << hbits;
+        for (uint32_t i = lane * 4; i < n; i += 256) *reinterpret_cast<uint4*>(tab + i) = uint4{~0u, ~0u, ~0u, ~0u};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the stores reach L2 ahead of the other lanes' atomics
+    }
+    __device__ __forceinline__ bool test_and_set(uint32_t id) {
+        const uint32_t mask = (1u << hbits) - 1u;
+        uint32_t s = (id * 0x9E3779B1u) >> (32u - hbits);
+        uint32_t old = atomicCAS(&tab[s], kEmptyWord, id);
+        while (old != kEmptyWord && old != id) {
+            s = (s + 1u) & mask;
+            old = atomicCAS(&tab[s], kEmptyWord, id);
+        }
+        return old == kEmptyWord;
+    }
+    __device__ __forceinline__ uint32_t limit() const { return (3u << hbits) >> 2; }
+};
+
 struct BitmapVisited {  // exact for any number of visited nodes; one n-bit map in HBM per resident wave
     uint32_t* bits;
     uint32_t words;
@@ -259,6 +284,7 @@ struct SearchArgs {
     uint32_t* out_stats;   // nullable [nq][4]
     const uint32_t* allow; // filtered search: bit i of word i/32 = node i may enter the results
     uint32_t* redo;        // [0] = count, [1] = queries that could not be answered, [2 + i] = query ids to re-run
+    uint32_t* ghash;       // global-hash configuration: [gridDim.x][1 << kGlobalHashBits]
     uint32_t* bitmaps;     // large configuration: [gridDim.x][bitmap_words]
     uint32_t* report;      // nullable, host-mapped: [0] = queries the fast configuration gave up on, [1] = nq
     uint32_t bitmap_words;
@@ -268,17 +294,23 @@ struct SearchArgs {
 // every admitted node is a candidate, only allowed ones are results (:340-343), the search stops when
 // the best candidate is beyond the ef-th RESULT (:316).  Restated on the one sorted array: see
 // KeyArray (S == 2) and DESIGN.md "Filtered search".
-template <int NCH, int GPB, int R, bool LARGE, bool IS_L2, bool FILT>
+// VIS: where the visited set lives - 0 hash in LDS (one query per block), 1 hash in HBM (persistent
+// blocks walking the batch), 2 exact bitmap in HBM = the large configuration over the re-run list.
+template <int NCH, int GPB, int R, int VIS, bool IS_L2, bool FILT>
 __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
     constexpr int S = FILT ? 2 : 1;
+    constexpr bool LARGE = VIS == 2;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = lane_id();
     const DevGraph& g = a.g;
 
-    typename std::conditional<LARGE, BitmapVisited, LdsVisited>::type vis;
+    typename std::conditional<LARGE, BitmapVisited, typename std::conditional<VIS == 1, GlobalHashVisited, LdsVisited>::type>::type vis;
     if constexpr (LARGE) {
         vis.bits = a.bitmaps + (size_t)blockIdx.x * a.bitmap_words;
         vis.words = a.bitmap_words;
+    } else if constexpr (VIS == 1) {
+        vis.tab = a.ghash + ((size_t)blockIdx.x << kGlobalHashBits);
+        vis.hbits = kGlobalHashBits;
     } else {
         vis.tab = lds;
         vis.hbits = a.hbits;
@@ -591,18 +623,42 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
     const size_t epilogue_bytes = (size_t)64 * R * 12;
     size_t lds_small = (size_t)4 << a.hbits;
     if (lds_small < epilogue_bytes) lds_small = epilogue_bytes;
-    if (a.g.metric == 0)
-        hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, false, true, FILT>), dim3(a.nq), dim3(64), lds_small, stream, a);
-    else
-        hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, false, false, FILT>), dim3(a.nq), dim3(64), lds_small, stream, a);
+    if constexpr (R >= 4 && !FILT) {
+        // an LDS table of 32 KB or more would leave five or fewer queries resident per CU
+        if (a.hbits >= 13 && a.ghash) {
+            // persistent blocks: as many as are resident at once, each with its own table
+            static const uint32_t resident = [&] {
+                int per_cu = 0, dev = 0;
+                hipDeviceProp_t prop;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hnsw_search_kernel<NCH, GPB, R, 1, true, FILT>, 64,
+                                                                 epilogue_bytes) != hipSuccess ||
+                    hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu <= 0)
+                    return 2048u;
+                return (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
+            }();
+            uint32_t blocks = resident < kGlobalHashBlocks ? resident : kGlobalHashBlocks;
+            if (a.nq < blocks) blocks = a.nq;
+            if (a.g.metric == 0)
+                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 1, true, FILT>), dim3(blocks), dim3(64), epilogue_bytes, stream, a);
+            else
+                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 1, false, FILT>), dim3(blocks), dim3(64), epilogue_bytes, stream, a);
+            lds_small = 0;
+        }
+    }
+    if (lds_small) {
+        if (a.g.metric == 0)
+            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 0, true, FILT>), dim3(a.nq), dim3(64), lds_small, stream, a);
+        else
+            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 0, false, FILT>), dim3(a.nq), dim3(64), lds_small, stream, a);
+    }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) {
         const uint32_t blocks = a.nq < kLargeBlocks ? a.nq : kLargeBlocks;
         if (a.g.metric == 0)
-            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, RL, true, true, FILT>), dim3(blocks), dim3(64),
+            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, RL, 2, true, FILT>), dim3(blocks), dim3(64),
                                (size_t)64 * RL * 12, stream, a);
         else
-            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, RL, true, false, FILT>), dim3(blocks), dim3(64),
+            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, RL, 2, false, FILT>), dim3(blocks), dim3(64),
                                (size_t)64 * RL * 12, stream, a);
         e = hipGetLastError();
     }
@@ -681,6 +737,7 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
     a.redo = work.redo;
     a.bitmaps = work.bitmaps;
     a.bitmap_words = work.bitmap_words;
+    a.ghash = work.ghash;
     a.report = work.report;
     hipError_t e = hipMemsetAsync(work.redo, 0, 2 * sizeof(uint32_t), stream);
     if (e != hipSuccess) {

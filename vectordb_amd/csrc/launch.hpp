@@ -13,9 +13,12 @@ namespace vdb {
 constexpr uint32_t kMaxEf = 508;           // sorted key array: up to 8 registers per lane (512 keys), 16 in the large configuration
 constexpr uint32_t kMaxVecStride = 1024;   // floats per row (16 chunks of 64)
 constexpr uint32_t kMaxL0Stride = 64;      // layer-0 list slots (maxM0 <= 64, i.e. M <= 32)
+constexpr uint32_t kGlobalHashBits = 15;     // 32 768 entries (128 KB) per resident wave: 24 576 visited nodes
+constexpr uint32_t kGlobalHashBlocks = 4096;  // resident waves of the global-hash configuration (512 MB of tables)
 constexpr uint32_t kLargeBlocks = 128;     // resident waves of the large configuration (one bitmap each)
 
 struct HnswSearchWork {
+    uint32_t* ghash = nullptr;    // nullable: [kGlobalHashBlocks << kGlobalHashBits] u32, visited tables in HBM (large ef)
     uint32_t* report = nullptr;   // nullable, host-mapped [2]: {queries re-run by the large configuration, nq} of this launch
     uint32_t hbits_bias = 0;      // added to log2 of the visited-set size the launcher picks
     uint32_t* redo = nullptr;     // [2 + nq] u32; [0] (re-run count) and [1] (unanswerable filtered queries) zeroed by the launcher
