@@ -113,7 +113,7 @@ def test_device_build_refuses_before_it_stores_anything():
     index is touched (there is no CPU fallback for the device builder)."""
     from vectordb_amd import _lib
     x = np.random.default_rng(0).random((100, 8), dtype=np.float32)
-    h = vi.HierarchicalNSW(vi.L2Space(8), 100, 16, 300, 100)      # ef_construction above the device limit
+    h = vi.HierarchicalNSW(vi.L2Space(8), 100, 16, 600, 100)      # ef_construction above the device limit (508)
     with pytest.raises(vi.VdbError) as e:
         h.add_items_device(x)
     assert e.value.code == _lib.VDB_ERR_UNSUPPORTED and h.getElementCount() == 0
