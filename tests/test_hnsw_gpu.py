@@ -83,17 +83,22 @@ def test_small_and_empty_indexes(orc):
     assert np.all(st[:, 3] == 7)
 
 
-def test_visited_overflow_falls_back_exactly(orc):
-    """ef large against a small hash is what the large configuration is for: ef=256 on a
-    graph of 6000 nodes visits most of it."""
+@pytest.mark.parametrize("nq,spill", [(32, True), (32, False), (700, True)])
+def test_visited_overflow_is_exact(orc, monkeypatch, nq, spill):
+    """ef=256 on a graph of 6000 nodes visits most of it: every query fills its LDS table.  With spill
+    tables it carries on in a second-level table in HBM; without (or once the 512 tables of a launch
+    are taken: nq=700) it is re-run by the large configuration (bitmap).  Same answers every way."""
+    if not spill:
+        monkeypatch.setenv("VDB_NO_SPILL", "1")
     x = datasets.uniform(6000, 16, 11)
-    q = datasets.uniform(32, 16, 12)
+    q = datasets.uniform(nq, 16, 12)
     h, o = build_pair(orc, x, vi.L2, 16, 64)
     h.to_device(0)
     h.setefSearch(256)
     o.set_ef(256)
-    dist, label, st = h.search_batch(q, 100, stats=True)
-    assert_same_results((dist, label), o.search(q, 100), st)
+    for _ in range(2):  # the second launch reuses the spill tables the first one left dirty
+        dist, label, st = h.search_batch(q, 100, stats=True)
+        assert_same_results((dist, label), o.search(q, 100), st)
 
 
 @pytest.mark.parametrize("ef,k", [(300, 300), (316, 100), (317, 10), (508, 508), (124, 124), (125, 100), (60, 60), (61, 50)])

@@ -102,6 +102,7 @@ size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 struct SearchScratch {
     DevBuf redo, bitmaps, allow;  // allow: delete flags AND the caller's filter, when both exist
     DevBuf ghash;                 // visited tables in HBM for the large-ef configuration (allocated on first need)
+    DevBuf spill;                 // second-level visited tables for the queries that fill their LDS table
     // host-mapped {re-run queries, nq} written by the last launch on this stream, and the ef it ran at:
     // read (without synchronising) before the next launch to size the visited set (see search_device)
     uint32_t* report = nullptr;
@@ -376,9 +377,10 @@ SearchScratch& scratch_for(vdb_index* idx, hipStream_t stream, size_t nq) {
     if (s.redo_cap < nq + 1) {
         // a previous call on this stream may still be using the old buffer
         if (s.redo.p) VDB_HIP(hipStreamSynchronize(stream));
-        s.redo.alloc((nq + 2) * 4 * 2);
-        s.redo_cap = (nq + 2) * 2 - 1;
+        s.redo.alloc((nq + kRedoHeader) * 4 * 2);
+        s.redo_cap = (nq + kRedoHeader) * 2 - kRedoHeader;
     }
+    if (!s.spill.p) s.spill.alloc(((size_t)kSpillTables << kSpillBits) * 4);
     const uint32_t words = (idx->graph.n + 31u) / 32u;
     if (!s.bitmaps.p || s.bitmap_words < words) {
         if (s.bitmaps.p) VDB_HIP(hipStreamSynchronize(stream));
@@ -442,6 +444,8 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
     }
     HnswSearchWork work;
     work.redo = (uint32_t*)s.redo.p;
+    // VDB_NO_SPILL=1 (tests): every query that fills its LDS table is re-run by the large configuration
+    work.spill = std::getenv("VDB_NO_SPILL") ? nullptr : (uint32_t*)s.spill.p;
     work.bitmaps = (uint32_t*)s.bitmaps.p;
     work.bitmap_words = s.bitmap_words;
     if (ef > 124 && !allow) {
@@ -622,6 +626,7 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
     }
     HnswSearchWork work;
     work.redo = (uint32_t*)sc->redo.p;
+    work.spill = (uint32_t*)sc->spill.p;
     work.bitmaps = (uint32_t*)sc->bitmaps.p;
     work.bitmap_words = sc->bitmap_words;
     // the visited-set size follows what the rounds report, as in search_device: the searches of a

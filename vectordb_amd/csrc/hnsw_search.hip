@@ -52,22 +52,58 @@ using namespace dev;
 struct LdsVisited {
     uint32_t* tab;
     uint32_t hbits;
+    // Second level, in HBM, taken when the LDS table reaches its fill limit (take_spill): the LDS
+    // table is then frozen (looked up, never inserted into) and new ids go to the spill table, so the
+    // set stays exact and the search carries on instead of starting again in the large configuration.
+    uint32_t* spill;
     __device__ __forceinline__ void clear(int lane) {
         const uint32_t n = 1u << hbits;
         for (uint32_t i = lane * 4; i < n; i += 256) *reinterpret_cast<uint4*>(tab + i) = uint4{~0u, ~0u, ~0u, ~0u};
+        spill = nullptr;
     }
     // true when `id` was not in the set (and inserts it)
     __device__ __forceinline__ bool test_and_set(uint32_t id) {
         const uint32_t mask = (1u << hbits) - 1u;
         uint32_t s = (id * 0x9E3779B1u) >> (32u - hbits);
-        uint32_t old = atomicCAS(&tab[s], kEmptyWord, id);  // almost always decides
-        while (old != kEmptyWord && old != id) {
+        if (spill == nullptr) {  // (wave-uniform)
+            uint32_t old = atomicCAS(&tab[s], kEmptyWord, id);  // almost always decides
+            while (old != kEmptyWord && old != id) {
+                s = (s + 1u) & mask;
+                old = atomicCAS(&tab[s], kEmptyWord, id);
+            }
+            return old == kEmptyWord;
+        }
+        uint32_t v = tab[s];  // frozen at 75 % fill or less: the probe ends
+        while (v != kEmptyWord && v != id) {
             s = (s + 1u) & mask;
-            old = atomicCAS(&tab[s], kEmptyWord, id);
+            v = tab[s];
+        }
+        if (v == id) return false;
+        constexpr uint32_t gmask = (1u << kSpillBits) - 1u;
+        s = (id * 0x9E3779B1u) >> (32u - kSpillBits);
+        uint32_t old = atomicCAS(&spill[s], kEmptyWord, id);
+        while (old != kEmptyWord && old != id) {
+            s = (s + 1u) & gmask;
+            old = atomicCAS(&spill[s], kEmptyWord, id);
         }
         return old == kEmptyWord;
     }
     __device__ __forceinline__ uint32_t limit() const { return (3u << hbits) >> 2; }  // 75 % fill
+    // Called by the whole wave when the next hop could pass the limit; `taken` = the launch's counter of
+    // spill tables.  Returns the new limit, or 0 when there is no table to take (none configured,
+    // all taken, or this query has one already).
+    __device__ __forceinline__ uint32_t take_spill(uint32_t* pool, uint32_t* taken, int lane) {
+        if (pool == nullptr || spill != nullptr) return 0u;
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(taken, 1u);
+        t = readlane(t, 0);
+        if (t >= kSpillTables) return 0u;
+        spill = pool + ((size_t)t << kSpillBits);
+        for (uint32_t i = lane * 4; i < (1u << kSpillBits); i += 256)
+            *reinterpret_cast<uint4*>(spill + i) = uint4{~0u, ~0u, ~0u, ~0u};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the stores reach L2 ahead of the other lanes' atomics
+        return limit() + ((3u << kSpillBits) >> 2);
+    }
 };
 
 // The same hash in HBM, one table per resident wave: for searches that visit thousands of nodes (large
@@ -283,7 +319,9 @@ struct SearchArgs {
     uint64_t* out_label;   // [nq][k]
     uint32_t* out_stats;   // nullable [nq][4]
     const uint32_t* allow; // filtered search: bit i of word i/32 = node i may enter the results
-    uint32_t* redo;        // [0] = count, [1] = queries that could not be answered, [2 + i] = query ids to re-run
+    uint32_t* redo;        // [0] = count, [1] = queries that could not be answered, [2] = spill tables taken,
+                           // [kRedoHeader + i] = query ids to re-run
+    uint32_t* spill;       // nullable: [kSpillTables << kSpillBits], see LdsVisited
     uint32_t* ghash;       // global-hash configuration: [gridDim.x][1 << kGlobalHashBits]
     uint32_t* bitmaps;     // large configuration: [gridDim.x][bitmap_words]
     uint32_t* report;      // nullable, host-mapped: [0] = queries the fast configuration gave up on, [1] = nq
@@ -319,13 +357,14 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
     const uint32_t n_work = LARGE ? a.redo[0] : a.nq;
     if constexpr (LARGE) {  // tells the host how the visited-set size chosen for this launch fared
         if (blockIdx.x == 0 && lane == 0 && a.report) {
-            a.report[0] = n_work;
+            const uint32_t spilled = a.redo[2] < kSpillTables ? a.redo[2] : kSpillTables;
+            a.report[0] = n_work + spilled;  // the queries that outgrew the LDS table, whichever way they went on
             a.report[1] = a.nq;
         }
     }
 #pragma unroll 1
     for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {
-        const uint32_t qi = LARGE ? a.redo[2 + w] : w;
+        const uint32_t qi = LARGE ? a.redo[kRedoHeader + w] : w;
         const uint32_t k = a.k, ef = a.ef;
         float* od = a.out_dist + (size_t)qi * k;
         uint64_t* ol = a.out_label + (size_t)qi * k;
@@ -415,7 +454,7 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
             }
             bound = ef > 1 ? kEmptyWord : cur_d;  // hi of entry ef-1
         }
-        uint32_t nvis = 1;
+        uint32_t nvis = 1, vis_limit = vis.limit();
         bool overflow = false;
         if (lane == 0) (void)vis.test_and_set(cur);
 
@@ -427,9 +466,14 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
 #pragma unroll 1
         while (FILT ? arr.pop_candidate_filtered(lane, cand) : arr.pop_candidate(lane, cand)) {
             hops0 += 1;
-            if (nvis + g.l0stride > vis.limit()) {
-                overflow = true;
-                break;
+            if (nvis + g.l0stride > vis_limit) {
+                uint32_t more = 0;
+                if constexpr (VIS == 0) more = vis.take_spill(a.spill, a.redo + 2, lane);
+                if (more == 0) {
+                    overflow = true;
+                    break;
+                }
+                vis_limit = more;
             }
             uint32_t nb;
             if (cand == pfa_id) nb = pfa_row;
@@ -505,7 +549,7 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
             if constexpr (!LARGE) {
                 if (lane == 0) {
                     const uint32_t slot = atomicAdd(&a.redo[0], 1u);
-                    a.redo[2 + slot] = qi;
+                    a.redo[kRedoHeader + slot] = qi;
                 }
                 continue;
             } else if constexpr (FILT) {
@@ -735,11 +779,12 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
     a.out_label = d_out_label;
     a.out_stats = d_out_stats;
     a.redo = work.redo;
+    a.spill = work.spill;
     a.bitmaps = work.bitmaps;
     a.bitmap_words = work.bitmap_words;
     a.ghash = work.ghash;
     a.report = work.report;
-    hipError_t e = hipMemsetAsync(work.redo, 0, 2 * sizeof(uint32_t), stream);
+    hipError_t e = hipMemsetAsync(work.redo, 0, kRedoHeader * sizeof(uint32_t), stream);
     if (e != hipSuccess) {
         if (err) *err = std::string("hipMemsetAsync: ") + hipGetErrorString(e);
         return 3;
