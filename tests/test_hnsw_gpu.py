@@ -83,22 +83,41 @@ def test_small_and_empty_indexes(orc):
     assert np.all(st[:, 3] == 7)
 
 
-@pytest.mark.parametrize("nq,spill", [(32, True), (32, False), (700, True)])
+@pytest.mark.parametrize("nq,spill", [(32, "1"), (32, "0"), (700, "1"), (32, None)])
 def test_visited_overflow_is_exact(orc, monkeypatch, nq, spill):
     """ef=256 on a graph of 6000 nodes visits most of it: every query fills its LDS table.  With spill
-    tables it carries on in a second-level table in HBM; without (or once the 512 tables of a launch
-    are taken: nq=700) it is re-run by the large configuration (bitmap).  Same answers every way."""
-    if not spill:
-        monkeypatch.setenv("VDB_NO_SPILL", "1")
+    tables ("1") it carries on in a second-level table in HBM; without ("0", or once the 512 tables of a
+    launch are taken: nq=700) it is re-run by the large configuration (bitmap).  Unset, the library
+    hands out the tables from the second launch on.  Same answers every way."""
+    if spill is None:
+        monkeypatch.delenv("VDB_SPILL", raising=False)
+    else:
+        monkeypatch.setenv("VDB_SPILL", spill)
     x = datasets.uniform(6000, 16, 11)
     q = datasets.uniform(nq, 16, 12)
     h, o = build_pair(orc, x, vi.L2, 16, 64)
     h.to_device(0)
     h.setefSearch(256)
     o.set_ef(256)
-    for _ in range(2):  # the second launch reuses the spill tables the first one left dirty
+    for _ in range(3):  # later launches adapt (spill tables, larger LDS table) and reuse dirty spill tables
         dist, label, st = h.search_batch(q, 100, stats=True)
         assert_same_results((dist, label), o.search(q, 100), st)
+
+
+@pytest.mark.parametrize("metric", [vi.L2, vi.IP])
+def test_spill_tables_at_small_ef(orc, monkeypatch, metric):
+    """ef=100 (two key registers per lane, 2^12-entry LDS table) on a dense small graph: some queries
+    spill, most do not - both in one launch."""
+    monkeypatch.setenv("VDB_SPILL", "1")
+    x = datasets.uniform(9000, 8, 21)
+    q = datasets.uniform(300, 8, 22)
+    h, o = build_pair(orc, x, metric, 32, 64)
+    h.to_device(0)
+    for ef in (100, 124):
+        h.setefSearch(ef)
+        o.set_ef(ef)
+        dist, label, st = h.search_batch(q, 10, stats=True)
+        assert_same_results((dist, label), o.search(q, 10), st)
 
 
 @pytest.mark.parametrize("ef,k", [(300, 300), (316, 100), (317, 10), (508, 508), (124, 124), (125, 100), (60, 60), (61, 50)])

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -125,6 +126,7 @@ struct vdb_index {
     DevBuf vecs, links0, upper_row, upper_links, labels;
     DevBuf live;  // bit i = element i is not deleted; allocated only when the upload saw deleted elements
     std::map<uint32_t, uint32_t> hbits_bias;  // per ef: extra log2 of the visited-set size (guarded by scratch_lock)
+    std::set<uint32_t> spill_ef;              // the ef values at which a launch had queries outgrow the LDS table (same lock)
     std::mutex scratch_lock;
     std::map<hipStream_t, std::unique_ptr<SearchScratch>> scratch;
 
@@ -435,6 +437,7 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
     {
         const uint32_t redone = ((volatile uint32_t*)s.report)[0], of = ((volatile uint32_t*)s.report)[1];
         if (of != 0 && s.report_ef != 0) {
+            if (redone != 0) idx->spill_ef.insert(s.report_ef);
             if ((uint64_t)redone * 50u > of) {
                 uint32_t& b = idx->hbits_bias[s.report_ef];
                 if (b < 3) b += 1;
@@ -444,8 +447,14 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
     }
     HnswSearchWork work;
     work.redo = (uint32_t*)s.redo.p;
-    // VDB_NO_SPILL=1 (tests): every query that fills its LDS table is re-run by the large configuration
-    work.spill = std::getenv("VDB_NO_SPILL") ? nullptr : (uint32_t*)s.spill.p;
+    // Spill tables (hnsw_search.hip, LdsVisited) go to the launches at an ef at which an earlier launch
+    // had queries outgrow the LDS table: the kernel variant that can spill is 1-5 % slower for the
+    // searches that never do.  VDB_SPILL=0 / 1 (tests) = never / always.
+    {
+        const char* force = std::getenv("VDB_SPILL");
+        const bool on = force ? force[0] == '1' : idx->spill_ef.count((uint32_t)ef) != 0;
+        work.spill = on ? (uint32_t*)s.spill.p : nullptr;
+    }
     work.bitmaps = (uint32_t*)s.bitmaps.p;
     work.bitmap_words = s.bitmap_words;
     if (ef > 124 && !allow) {
@@ -626,7 +635,6 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
     }
     HnswSearchWork work;
     work.redo = (uint32_t*)sc->redo.p;
-    work.spill = (uint32_t*)sc->spill.p;
     work.bitmaps = (uint32_t*)sc->bitmaps.p;
     work.bitmap_words = sc->bitmap_words;
     // the visited-set size follows what the rounds report, as in search_device: the searches of a
@@ -648,6 +656,7 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
         {
             const uint32_t redone = ((volatile uint32_t*)sc->report)[0], of = ((volatile uint32_t*)sc->report)[1];
             if (of != 0) {
+                if (redone != 0) work.spill = (uint32_t*)sc->spill.p;  // as in search_device
                 if ((uint64_t)redone * 50u > of && work.hbits_bias < 3) work.hbits_bias += 1;
                 ((volatile uint32_t*)sc->report)[1] = 0;
             }

@@ -49,6 +49,8 @@ using namespace dev;
 
 // ------------------------------------------------------------------ visited set
 
+// SPILL = a second level in HBM may be taken; without it the code is the plain LDS hash
+template <bool SPILL>
 struct LdsVisited {
     uint32_t* tab;
     uint32_t hbits;
@@ -65,7 +67,7 @@ struct LdsVisited {
     __device__ __forceinline__ bool test_and_set(uint32_t id) {
         const uint32_t mask = (1u << hbits) - 1u;
         uint32_t s = (id * 0x9E3779B1u) >> (32u - hbits);
-        if (spill == nullptr) {  // (wave-uniform)
+        if (!SPILL || spill == nullptr) {  // (wave-uniform)
             uint32_t old = atomicCAS(&tab[s], kEmptyWord, id);  // almost always decides
             while (old != kEmptyWord && old != id) {
                 s = (s + 1u) & mask;
@@ -93,7 +95,7 @@ struct LdsVisited {
     // spill tables.  Returns the new limit, or 0 when there is no table to take (none configured,
     // all taken, or this query has one already).
     __device__ __forceinline__ uint32_t take_spill(uint32_t* pool, uint32_t* taken, int lane) {
-        if (pool == nullptr || spill != nullptr) return 0u;
+        if (!SPILL || pool == nullptr || spill != nullptr) return 0u;
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(taken, 1u);
         t = readlane(t, 0);
@@ -333,7 +335,8 @@ struct SearchArgs {
 // the best candidate is beyond the ef-th RESULT (:316).  Restated on the one sorted array: see
 // KeyArray (S == 2) and DESIGN.md "Filtered search".
 // VIS: where the visited set lives - 0 hash in LDS (one query per block), 1 hash in HBM (persistent
-// blocks walking the batch), 2 exact bitmap in HBM = the large configuration over the re-run list.
+// blocks walking the batch), 2 exact bitmap in HBM = the large configuration over the re-run list,
+// 3 = 0 with a second-level table in HBM for the queries that fill the LDS one (LdsVisited).
 template <int NCH, int GPB, int R, int VIS, bool IS_L2, bool FILT>
 __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
     constexpr int S = FILT ? 2 : 1;
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
     const int lane = lane_id();
     const DevGraph& g = a.g;
 
-    typename std::conditional<LARGE, BitmapVisited, typename std::conditional<VIS == 1, GlobalHashVisited, LdsVisited>::type>::type vis;
+    typename std::conditional<LARGE, BitmapVisited, typename std::conditional<VIS == 1, GlobalHashVisited, LdsVisited<VIS == 3>>::type>::type vis;
     if constexpr (LARGE) {
         vis.bits = a.bitmaps + (size_t)blockIdx.x * a.bitmap_words;
         vis.words = a.bitmap_words;
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
             hops0 += 1;
             if (nvis + g.l0stride > vis_limit) {
                 uint32_t more = 0;
-                if constexpr (VIS == 0) more = vis.take_spill(a.spill, a.redo + 2, lane);
+                if constexpr (VIS == 3) more = vis.take_spill(a.spill, a.redo + 2, lane);
                 if (more == 0) {
                     overflow = true;
                     break;
@@ -690,7 +693,14 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
         }
     }
     if (lds_small) {
-        if (a.g.metric == 0)
+        // the spill variant costs the searches that never spill 1-5 % (a uniform branch per hop in the
+        // hash probe): the caller passes the tables only when earlier launches at this ef needed them
+        if (a.spill) {
+            if (a.g.metric == 0)
+                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 3, true, FILT>), dim3(a.nq), dim3(64), lds_small, stream, a);
+            else
+                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 3, false, FILT>), dim3(a.nq), dim3(64), lds_small, stream, a);
+        } else if (a.g.metric == 0)
             hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 0, true, FILT>), dim3(a.nq), dim3(64), lds_small, stream, a);
         else
             hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 0, false, FILT>), dim3(a.nq), dim3(64), lds_small, stream, a);
