@@ -40,6 +40,9 @@ def log(*a):
 
 
 def main() -> None:
+    if os.environ.get("VDB_BENCH_WATCHDOG"):  # diagnostics: dump every thread's stack after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["VDB_BENCH_WATCHDOG"]), exit=False)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -189,8 +192,11 @@ def main() -> None:
     if world > 1 and not args.no_sharded:
         from vectordb_amd import sharding
         per = (args.n + world - 1) // world
+        log(f"replicas: {qps:.3e} queries/s over {world} ranks; building the {per}-row shards for the sharded variant")
+        t0 = time.time()
         hs = sharding.build_shard(base, world, rank, vi.L2, args.M, args.efc, n_threads=threads)
         hs.to_device(local_rank)
+        log(f"shard graph built in {time.time() - t0:.1f}s")
         hs.setefSearch(chosen)
         shared_q = torch.from_numpy(law.sample(args.nq, seed=2)).to(dev)   # the SAME batch on every rank
 
@@ -201,6 +207,7 @@ def main() -> None:
         torch.cuda.synchronize()
         # rank 0's ground truth is for its own batch == seed 2 == the shared batch
         srec = datasets.recall_at_k(ml.cpu().numpy().view(np.uint64), gt) if rank == 0 else 0.0
+        log(f"sharded search + all-gather + merge: recall@{args.k} {srec:.4f}")
         for _ in range(args.warmup):
             sharded_step()
         barrier()

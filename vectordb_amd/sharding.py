@@ -50,6 +50,11 @@ def all_gather_results(dist, label):
 
     world = td.get_world_size()
     nq = dist.shape[0]
+    if dist.is_cuda and td.get_backend() == "gloo":
+        # gloo on GPU tensors (only the one-GPU rehearsal of bench.py does this) stalls after the first
+        # call with two ranks on one device: stage through the host there
+        gd, gl = all_gather_results(dist.cpu(), label.cpu())
+        return gd.to(dist.device), gl.to(label.device)
     gd = torch.empty((world * nq,) + tuple(dist.shape[1:]), dtype=dist.dtype, device=dist.device)
     gl = torch.empty((world * nq,) + tuple(label.shape[1:]), dtype=label.dtype, device=label.device)
     td.all_gather_into_tensor(gd, dist.contiguous())   # concatenation along dim 0 == [world][nq][k]
