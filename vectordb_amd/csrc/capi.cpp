@@ -104,6 +104,7 @@ struct SearchScratch {
     DevBuf redo, bitmaps, allow;  // allow: delete flags AND the caller's filter, when both exist
     DevBuf ghash;                 // visited tables in HBM for the large-ef configuration (allocated on first need)
     DevBuf spill;                 // second-level visited tables for the queries that fill their LDS table
+    uint32_t spill_tables = 0;
     // host-mapped {re-run queries, nq} written by the last launch on this stream, and the ef it ran at:
     // read (without synchronising) before the next launch to size the visited set (see search_device)
     uint32_t* report = nullptr;
@@ -382,7 +383,12 @@ SearchScratch& scratch_for(vdb_index* idx, hipStream_t stream, size_t nq) {
         s.redo.alloc((nq + kRedoHeader) * 4 * 2);
         s.redo_cap = (nq + kRedoHeader) * 2 - kRedoHeader;
     }
-    if (!s.spill.p) s.spill.alloc(((size_t)kSpillTables << kSpillBits) * 4);
+    const uint32_t tables = (uint32_t)std::min<size_t>(std::max<size_t>(nq / 16, kSpillTablesMin), kSpillTablesMax);
+    if (s.spill_tables < tables) {
+        if (s.spill.p) VDB_HIP(hipStreamSynchronize(stream));
+        s.spill.alloc(((size_t)tables << kSpillBits) * 4);
+        s.spill_tables = tables;
+    }
     const uint32_t words = (idx->graph.n + 31u) / 32u;
     if (!s.bitmaps.p || s.bitmap_words < words) {
         if (s.bitmaps.p) VDB_HIP(hipStreamSynchronize(stream));
@@ -454,6 +460,7 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
         const char* force = std::getenv("VDB_SPILL");
         const bool on = force ? force[0] == '1' : idx->spill_ef.count((uint32_t)ef) != 0;
         work.spill = on ? (uint32_t*)s.spill.p : nullptr;
+        work.spill_tables = s.spill_tables;
     }
     work.bitmaps = (uint32_t*)s.bitmaps.p;
     work.bitmap_words = s.bitmap_words;
@@ -656,7 +663,10 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
         {
             const uint32_t redone = ((volatile uint32_t*)sc->report)[0], of = ((volatile uint32_t*)sc->report)[1];
             if (of != 0) {
-                if (redone != 0) work.spill = (uint32_t*)sc->spill.p;  // as in search_device
+                if (redone != 0) {  // as in search_device
+                    work.spill = (uint32_t*)sc->spill.p;
+                    work.spill_tables = sc->spill_tables;
+                }
                 if ((uint64_t)redone * 50u > of && work.hbits_bias < 3) work.hbits_bias += 1;
                 ((volatile uint32_t*)sc->report)[1] = 0;
             }

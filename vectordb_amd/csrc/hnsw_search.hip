@@ -94,12 +94,12 @@ struct LdsVisited {
     // Called by the whole wave when the next hop could pass the limit; `taken` = the launch's counter of
     // spill tables.  Returns the new limit, or 0 when there is no table to take (none configured,
     // all taken, or this query has one already).
-    __device__ __forceinline__ uint32_t take_spill(uint32_t* pool, uint32_t* taken, int lane) {
+    __device__ __forceinline__ uint32_t take_spill(uint32_t* pool, uint32_t tables, uint32_t* taken, int lane) {
         if (!SPILL || pool == nullptr || spill != nullptr) return 0u;
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(taken, 1u);
         t = readlane(t, 0);
-        if (t >= kSpillTables) return 0u;
+        if (t >= tables) return 0u;
         spill = pool + ((size_t)t << kSpillBits);
         for (uint32_t i = lane * 4; i < (1u << kSpillBits); i += 256)
             *reinterpret_cast<uint4*>(spill + i) = uint4{~0u, ~0u, ~0u, ~0u};
@@ -323,7 +323,8 @@ struct SearchArgs {
     const uint32_t* allow; // filtered search: bit i of word i/32 = node i may enter the results
     uint32_t* redo;        // [0] = count, [1] = queries that could not be answered, [2] = spill tables taken,
                            // [kRedoHeader + i] = query ids to re-run
-    uint32_t* spill;       // nullable: [kSpillTables << kSpillBits], see LdsVisited
+    uint32_t* spill;       // nullable: [spill_tables << kSpillBits], see LdsVisited
+    uint32_t spill_tables;
     uint32_t* ghash;       // global-hash configuration: [gridDim.x][1 << kGlobalHashBits]
     uint32_t* bitmaps;     // large configuration: [gridDim.x][bitmap_words]
     uint32_t* report;      // nullable, host-mapped: [0] = queries the fast configuration gave up on, [1] = nq
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
     const uint32_t n_work = LARGE ? a.redo[0] : a.nq;
     if constexpr (LARGE) {  // tells the host how the visited-set size chosen for this launch fared
         if (blockIdx.x == 0 && lane == 0 && a.report) {
-            const uint32_t spilled = a.redo[2] < kSpillTables ? a.redo[2] : kSpillTables;
+            const uint32_t spilled = a.redo[2] < a.spill_tables ? a.redo[2] : a.spill_tables;
             a.report[0] = n_work + spilled;  // the queries that outgrew the LDS table, whichever way they went on
             a.report[1] = a.nq;
         }
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
             hops0 += 1;
             if (nvis + g.l0stride > vis_limit) {
                 uint32_t more = 0;
-                if constexpr (VIS == 3) more = vis.take_spill(a.spill, a.redo + 2, lane);
+                if constexpr (VIS == 3) more = vis.take_spill(a.spill, a.spill_tables, a.redo + 2, lane);
                 if (more == 0) {
                     overflow = true;
                     break;
@@ -789,7 +790,8 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
     a.out_label = d_out_label;
     a.out_stats = d_out_stats;
     a.redo = work.redo;
-    a.spill = work.spill;
+    a.spill = work.spill_tables ? work.spill : nullptr;
+    a.spill_tables = work.spill ? work.spill_tables : 0u;
     a.bitmaps = work.bitmaps;
     a.bitmap_words = work.bitmap_words;
     a.ghash = work.ghash;

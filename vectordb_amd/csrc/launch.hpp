@@ -17,7 +17,8 @@ constexpr uint32_t kGlobalHashBits = 15;     // 32 768 entries (128 KB) per resi
 constexpr uint32_t kGlobalHashBlocks = 4096;  // resident waves of the global-hash configuration (512 MB of tables)
 constexpr uint32_t kLargeBlocks = 128;     // resident waves of the large configuration (one bitmap each)
 constexpr uint32_t kSpillBits = 14;        // 16 384 entries (64 KB) per spill table: 12 288 more visited nodes
-constexpr uint32_t kSpillTables = 512;     // spill tables per launch (32 MB); a query that finds none left is re-run
+constexpr uint32_t kSpillTablesMin = 512;  // spill tables per launch: nq / 16 within [512, 4096] (32-256 MB); a query that
+constexpr uint32_t kSpillTablesMax = 4096; // finds none left is re-run by the large configuration
 constexpr uint32_t kRedoHeader = 4;        // words ahead of the re-run list
 
 struct HnswSearchWork {
@@ -26,7 +27,8 @@ struct HnswSearchWork {
     uint32_t hbits_bias = 0;      // added to log2 of the visited-set size the launcher picks
     uint32_t* redo = nullptr;     // [kRedoHeader + nq] u32; the header ([0] re-run count, [1] unanswerable filtered queries,
                                   // [2] spill tables taken, [3] unused) is zeroed by the launcher
-    uint32_t* spill = nullptr;    // nullable: [kSpillTables << kSpillBits] u32, second-level visited tables in HBM for the
+    uint32_t spill_tables = 0;
+    uint32_t* spill = nullptr;    // nullable: [spill_tables << kSpillBits] u32, second-level visited tables in HBM for the
                                   // queries that fill their LDS table (any contents: a table is cleared when taken)
     uint32_t* bitmaps = nullptr;  // [kLargeBlocks][bitmap_words]
     uint32_t bitmap_words = 0;
