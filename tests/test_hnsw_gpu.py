@@ -104,6 +104,29 @@ def test_visited_overflow_is_exact(orc, monkeypatch, nq, spill):
         assert_same_results((dist, label), o.search(q, 100), st)
 
 
+def test_spill_pool_grows_with_the_batch(orc, monkeypatch):
+    """The pool holds one spill table per 16 queries of the largest batch (512 to 4096): a 20 000-query
+    batch after a small one re-allocates it, 1 250 queries carry on in spill tables and the rest are
+    re-run by the large configuration.  Both ways are exact, so the answers equal those of a run without
+    spill tables, and the oracle's on a sample."""
+    x = datasets.uniform(6000, 16, 11)
+    q = datasets.uniform(20000, 16, 31)
+    h, o = build_pair(orc, x, vi.L2, 16, 64)
+    h.to_device(0)
+    h.setefSearch(256)
+    o.set_ef(256)
+    monkeypatch.setenv("VDB_SPILL", "1")
+    h.search_batch(q[:32], 100)
+    d1, l1, st1 = h.search_batch(q, 100, stats=True)
+    monkeypatch.setenv("VDB_SPILL", "0")
+    d0, l0, st0 = h.search_batch(q, 100, stats=True)
+    np.testing.assert_array_equal(l1, l0)
+    np.testing.assert_array_equal(d1.view(np.uint32), d0.view(np.uint32))
+    np.testing.assert_array_equal(st1, st0)
+    sample = np.arange(0, 20000, 100)
+    assert_same_results((d1[sample], l1[sample]), o.search(q[sample], 100), st1[sample])
+
+
 @pytest.mark.parametrize("metric", [vi.L2, vi.IP])
 def test_spill_tables_at_small_ef(orc, monkeypatch, metric):
     """ef=100 (two key registers per lane, 2^12-entry LDS table) on a dense small graph: some queries
