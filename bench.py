@@ -1,19 +1,25 @@
 #!/usr/bin/env python3
 """bench.py — queries/sec of the HNSW k-NN query path on MI355X (BASELINE.json metric).
 
-Workload at any N: BASELINE.json configs[1] — 1M x 128 fp32 "SIFT-like" synthetic base set,
-HNSW M=16 efConstruction=200, batches of 10 000 queries, k=10, ef = the smallest value of
-the sweep {32,64,96,128,192,256} whose recall@10 against exact brute force is >= 0.95.
+Default workload (any N): BASELINE.json configs[1] — 1M x 128 fp32 "SIFT-like" synthetic base set,
+HNSW M=16 efConstruction=200, batches of 10 000 queries, k=10, ef = the smallest value of the sweep
+{32,64,96,128,192,256} whose recall@10 against exact brute force is >= 0.95.
 
-A "step" is one pass of the hot path (vdb_search_batch_device: greedy descent + layer-0 beam
-search + top-k output) over one batch of 10 000 queries already resident in HBM.
+A "step" is one pass of the hot path (vdb_search_batch_device: greedy descent + layer-0 beam search
++ top-k output) over one batch of 10 000 queries already resident in HBM.
 
-N > 1 (one process per GPU, torch.distributed / RCCL): the independent units of the path
-are the queries, so every rank holds a replica of the index and searches its own batch of
-10 000 queries ("weak": per-GPU work fixed); no collective sits on the data path.  The
-sharded variant of the north star (base set split over the ranks, per-rank top-k lists
-all-gathered over RCCL and merged on the GPU) is timed in the same run and reported under
-"sharded" — its queries/sec is by construction not additive over ranks.
+At N = 1 the same JSON line also carries a "bruteforce" block: BASELINE.json configs[2] (exact k-NN
+1M x 960, 10 000 queries, k=10) on the MFMA path in f32 and bf16, with its own roofline and CPU
+baseline (the other half of the metric: "% HBM/MFMA roofline").
+
+N > 1 (one process per GPU, torch.distributed / RCCL).  configs[1] fits one GPU, so `value` is
+what a deployment would run for it: a replica of the index per rank, every rank its own batch of
+10 000 queries ("weak": per-GPU work fixed), no collective on the data path.  The base-set sharding
+of the north star (each rank its own sub-graph, per-rank top-k lists all-gathered over RCCL, merged
+on the GPU) is timed in the same run under "sharded" with the step split into search / all-gather /
+merge.  `--workload c4` / `c5` are the configurations that only exist sharded (10M x 96 inner
+product, 100M x 128 k=100): there the sharded step IS the step, `value` is its queries/sec, and
+scaling is "strong" (the base set is fixed, each rank builds 1/N of it on its GPU).
 
 Prints ONE JSON line on rank 0.
 """
@@ -21,6 +27,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import tempfile
@@ -32,11 +39,102 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 EF_SWEEP = (32, 64, 96, 128, 192, 256)
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+MFMA_PEAK_TF = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense peaks, TFLOP/s
 
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def host_cores() -> dict:
+    """The host cores this process may use.  The GPU box is a shared machine: os.cpu_count() shows
+    every CPU of the host, the job's share is what its affinity mask, its cgroup CPU quota and the
+    thread-count variable the box exports (OMP_NUM_THREADS) allow, whichever is smallest."""
+    visible = os.cpu_count() or 1
+    limits = {"cpu_count": visible}
+    try:
+        limits["affinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                limits["cgroup_quota"] = max(1, math.ceil(int(quota) / int(period)))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            limits["cgroup_quota"] = max(1, math.ceil(q / p))
+    except (OSError, ValueError):
+        pass
+    omp = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    if omp > 0:
+        limits["OMP_NUM_THREADS"] = omp
+    share = min(limits.values())
+    return {"cores": share, "host_cpus_visible": visible, "limits": limits}
+
+
+class Dist:
+    """torch.distributed, or nothing at N = 1.  In rehearsal mode (several ranks on ONE GPU over gloo,
+    VDB_BENCH_REHEARSAL=1) every collective runs on CPU tensors."""
+
+    def __init__(self, world: int, rehearsal: bool, dev):
+        self.world, self.rehearsal, self.dev = world, rehearsal, dev
+        if world > 1:
+            import torch.distributed as dist
+            self.d = dist
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
+
+    def barrier(self):
+        import torch
+        torch.cuda.synchronize()
+        if self.world > 1:
+            self.d.barrier()
+        torch.cuda.synchronize()
+
+    def reduce(self, value: float, op: str = "max") -> float:
+        if self.world == 1:
+            return value
+        import torch
+        t = torch.tensor([value], dtype=torch.float64, device="cpu" if self.rehearsal else self.dev)
+        self.d.all_reduce(t, op={"max": self.d.ReduceOp.MAX, "sum": self.d.ReduceOp.SUM, "min": self.d.ReduceOp.MIN}[op])
+        return float(t.item())
+
+    def gather_objects(self, obj):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self.d.all_gather_object(out, obj)
+        return out
+
+    def close(self):
+        if self.world > 1:
+            self.d.destroy_process_group()
+
+
+def timed_sharded_steps(sharding, hs, shared_q, k, steps, warmup, dd):
+    """W + K sharded steps; per-step ms split into search / all-gather / merge (HIP events on the
+    launch stream, mean over the K steps, max over ranks) and the wall time of the K steps."""
+    import torch
+    for _ in range(warmup):
+        sharding.sharded_search(hs, shared_q, k)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+    dd.barrier()
+    t0 = time.perf_counter()
+    for e in ev:
+        out = sharding.sharded_search(hs, shared_q, k, events=e)
+    dd.barrier()
+    wall = dd.reduce(time.perf_counter() - t0)
+    parts = [float(np.mean([e[i].elapsed_time(e[i + 1]) for e in ev])) for i in range(3)]
+    parts = [dd.reduce(p) for p in parts]
+    return wall, {"search": round(parts[0], 4), "all_gather": round(parts[1], 4), "merge": round(parts[2], 4)}, out
 
 
 def main() -> None:
@@ -47,29 +145,28 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--base-rows", dest="n", type=int, default=1_000_000, help="base vectors (default = the named workload)")
-    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--base-rows", dest="n", type=int, default=0, help="base vectors (default = the named workload's)")
+    ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--queries", dest="nq", type=int, default=10_000)
-    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--M", type=int, default=16)
     ap.add_argument("--efc", type=int, default=200)
+    ap.add_argument("--ef", type=int, default=0, help="c4/c5: the efSearch to time (default 48 / 200)")
     ap.add_argument("--build-threads", type=int, default=0)
-    ap.add_argument("--cpu-queries", type=int, default=2000, help="bounded sample of the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=1.0, help="wall seconds the cpu_baseline leg aims at (all host cores busy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sharded", action="store_true")
-    ap.add_argument("--workload", choices=("hnsw", "bruteforce"), default="hnsw",
-                    help="hnsw = BASELINE.json configs[1] (the headline metric); bruteforce = configs[2] "
-                         "(exact k-NN 1M x 960 on the MFMA path, its own JSON line)")
+    ap.add_argument("--no-bruteforce", action="store_true", help="skip the configs[2] block of the default line")
+    ap.add_argument("--workload", choices=("hnsw", "bruteforce", "c4", "c5"), default="hnsw",
+                    help="hnsw = BASELINE.json configs[1] (the headline metric, + the configs[2] block at N=1); "
+                         "bruteforce = configs[2] alone; c4 / c5 = the sharded configurations configs[3] / configs[4]")
     ap.add_argument("--precision", choices=("fp32", "bf16", "bf16_rerank"), default="bf16_rerank")
     ap.add_argument("--build", choices=("host", "device"), default="host",
                     help="graph builder: host = the reference algorithm on the host cores (default: the graph the headline\n"
                          "number is quoted on), device = vdb_index_add_batch_device (DESIGN.md 4.3)")
     args = ap.parse_args()
-    if args.workload == "bruteforce":
-        return run_bruteforce(args)
 
     import torch
-    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -82,34 +179,49 @@ def main() -> None:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dd = Dist(world, rehearsal, dev)
+    cores = host_cores()
+    threads = args.build_threads or cores["cores"]
     if world > 1:
-        if rehearsal:
-            dist.init_process_group("gloo")
+        threads = max(1, threads // (world if rehearsal else 1))
+    try:
+        if args.workload == "bruteforce":
+            if world != 1:
+                raise SystemExit("--workload bruteforce is a single-GPU line")
+            out = run_bruteforce(args, dev, cores, threads, standalone=True)
+        elif args.workload in ("c4", "c5"):
+            out = run_sharded_workload(args, dd, rank, local_rank, world, dev, cores, threads)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            out = run_hnsw(args, dd, rank, local_rank, world, dev, cores, threads)
+        if rank == 0 and out is not None:
+            print(json.dumps(out), flush=True)
+    finally:
+        dd.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# configs[1]: the headline
+# ------------------------------------------------------------------------------------------------
+
+def run_hnsw(args, dd, rank, local_rank, world, dev, cores, threads):
+    import torch
 
     from vectordb_amd import datasets
     from vectordb_amd import index as vi
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    threads = args.build_threads or int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
-    threads = max(1, min(threads, 16))
+    n, dim, k = args.n or 1_000_000, args.dim or 128, args.k or 10
 
     # ---- synthetic data -------------------------------------------
     t0 = time.time()
-    law = datasets.ClusteredLaw(args.dim, latent=32)
-    base = law.sample(args.n, seed=1)
+    law = datasets.ClusteredLaw(dim, latent=32)
+    base = law.sample(n, seed=1)
     queries = law.sample(args.nq, seed=2 + rank)          # every rank its own batch
     if rank == 0:
-        log(f"data {base.shape} + {queries.shape} in {time.time() - t0:.1f}s")
+        log(f"data {base.shape} + {queries.shape} in {time.time() - t0:.1f}s; host cores {cores}")
 
     # ---- graph build on the host cores (reference algorithm), upload ------------------
     t0 = time.time()
-    h = vi.HierarchicalNSW(vi.L2Space(args.dim), args.n, args.M, args.efc, 100)
+    h = vi.HierarchicalNSW(vi.L2Space(dim), n, args.M, args.efc, 100)
     if args.build == "device":
         h.add_items_device(base, n_threads=threads, device=local_rank)
     else:
@@ -125,10 +237,10 @@ def main() -> None:
 
     # ---- ground truth by the exact brute-force kernels --------------------------------
     t0 = time.time()
-    bf = vi.BruteforceSearch(vi.L2Space(args.dim), args.n)
+    bf = vi.BruteforceSearch(vi.L2Space(dim), n)
     bf.add_items(base)
     bf.to_device(local_rank)
-    gt_d, gt_l = bf.search_batch(dq, args.k)
+    gt_d, gt_l = bf.search_batch(dq, k)
     torch.cuda.synchronize()
     gt = gt_l.cpu().numpy().view(np.uint64)
     del bf
@@ -139,10 +251,10 @@ def main() -> None:
     sweep = {}
     chosen = None
     for ef in EF_SWEEP:
-        if ef < args.k:
+        if ef < k:
             continue
         h.setefSearch(ef)
-        _, lab = h.search_batch(dq, args.k)
+        _, lab = h.search_batch(dq, k)
         torch.cuda.synchronize()
         rec = datasets.recall_at_k(lab.cpu().numpy().view(np.uint64), gt)
         sweep[ef] = round(rec, 4)
@@ -151,75 +263,62 @@ def main() -> None:
             break
     if chosen is None:
         chosen = max(sweep)
-    if world > 1:  # all ranks time the same ef: the largest any rank needs
-        t = torch.tensor([chosen], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        chosen = int(t.item())
+    chosen = int(dd.reduce(float(chosen)))  # all ranks time the same ef: the largest any rank needs
     h.setefSearch(chosen)
-    dist_out, lab, st = h.search_batch(dq, args.k, stats=True)
+    dist_out, lab, st = h.search_batch(dq, k, stats=True)
     torch.cuda.synchronize()
     recall = datasets.recall_at_k(lab.cpu().numpy().view(np.uint64), gt)
     st = st.cpu().numpy().view(np.uint32).astype(np.int64)
     # algorithmic bytes of one launch: vectors scored, link rows read, query, output
     maxM0, maxM = 2 * args.M, args.M
-    alg_bytes = int((st[:, 0] * 4 * args.dim + st[:, 1] * 4 * (maxM0 + 1) + st[:, 2] * 4 * (maxM + 1)).sum()
-                    + args.nq * (4 * args.dim + args.k * 12))
+    alg_bytes = int((st[:, 0] * 4 * dim + st[:, 1] * 4 * (maxM0 + 1) + st[:, 2] * 4 * (maxM + 1)).sum()
+                    + args.nq * (4 * dim + k * 12))
     if rank == 0:
-        log(f"ef sweep {sweep} -> ef={chosen}, recall@{args.k}={recall:.4f}, mean ndis {st[:, 0].mean():.0f}, "
+        log(f"ef sweep {sweep} -> ef={chosen}, recall@{k}={recall:.4f}, mean ndis {st[:, 0].mean():.0f}, "
             f"mean hops {st[:, 1].mean():.1f}, {alg_bytes / 1e9:.2f} GB algorithmic per launch")
 
     # ---- timed region: W warm-up + K steps, barrier + synchronize on both sides --------
     for _ in range(args.warmup):
-        h.search_batch(dq, args.k)
+        h.search_batch(dq, k)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
+    dd.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record()          # same stream the kernels are enqueued on (torch's current stream)
-        h.search_batch(dq, args.k)
+        h.search_batch(dq, k)
         ev[i][1].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    dd.barrier()
+    elapsed = dd.reduce(time.perf_counter() - t0)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     qps = world * args.nq * args.steps / elapsed
+    if rank == 0:
+        log(f"timed: {elapsed / args.steps * 1e3:.4f} ms per step, {qps:.4e} queries/s over {world} rank(s)")
 
     # ---- sharded variant (north star): base split over ranks + RCCL all-gather + merge --
     sharded = None
     if world > 1 and not args.no_sharded:
         from vectordb_amd import sharding
-        per = (args.n + world - 1) // world
-        log(f"replicas: {qps:.3e} queries/s over {world} ranks; building the {per}-row shards for the sharded variant")
+        per = (n + world - 1) // world
+        log(f"rank {rank}: building its {per}-row shard ({args.build} builder)")
         t0 = time.time()
-        hs = sharding.build_shard(base, world, rank, vi.L2, args.M, args.efc, n_threads=threads)
+        hs = sharding.build_shard(base, world, rank, vi.L2, args.M, args.efc, n_threads=threads,
+                                  device_build=local_rank if args.build == "device" else None)
         hs.to_device(local_rank)
-        log(f"shard graph built in {time.time() - t0:.1f}s")
+        shard_build_s = dd.reduce(time.time() - t0)
         hs.setefSearch(chosen)
         shared_q = torch.from_numpy(law.sample(args.nq, seed=2)).to(dev)   # the SAME batch on every rank
-
-        def sharded_step():
-            return sharding.sharded_search(hs, shared_q, args.k)
-
-        md, ml = sharded_step()
+        md, ml = sharding.sharded_search(hs, shared_q, k)
         torch.cuda.synchronize()
         # rank 0's ground truth is for its own batch == seed 2 == the shared batch
         srec = datasets.recall_at_k(ml.cpu().numpy().view(np.uint64), gt) if rank == 0 else 0.0
-        log(f"sharded search + all-gather + merge: recall@{args.k} {srec:.4f}")
-        for _ in range(args.warmup):
-            sharded_step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            sharded_step()
-        barrier()
-        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        sharded = {"queries_per_s": round(args.nq * args.steps / float(t.item()), 1), "recall_at_k": round(srec, 4),
-                   "shards": world, "rows_per_shard": per, "ef": chosen,
-                   "exchange": "RCCL all_gather of [nq,k] (f32 dist, u64 label) + merge_topk kernel"}
+        log(f"rank {rank}: sharded search + all-gather + merge ok" + (f", recall@{k} {srec:.4f}" if rank == 0 else ""))
+        wall, split, _ = timed_sharded_steps(sharding, hs, shared_q, k, args.steps, args.warmup, dd)
+        ranks = dd.gather_objects({"rank": rank, "device": torch.cuda.current_device(), "host": os.uname().nodename})
+        sharded = {"queries_per_s": round(args.nq * args.steps / wall, 1), "ms_per_step": round(wall / args.steps * 1e3, 4),
+                   "ms_split_max_over_ranks": split, "recall_at_k": round(srec, 4),
+                   "shards": world, "rows_per_shard": per, "ef": chosen, "shard_build_seconds": round(shard_build_s, 1),
+                   "world_size": dd.d.get_world_size(), "backend": dd.d.get_backend(), "ranks": ranks,
+                   "exchange": "all_gather_into_tensor of [nq,k] f32 dist + [nq,k] u64 label, then merge_topk kernel"}
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on the host cores --
     cpu = None
@@ -229,149 +328,263 @@ def main() -> None:
         with tempfile.TemporaryDirectory() as d:
             path = os.path.join(d, "bench_index.bin")
             h.saveIndex(path)
-            o = orc.OracleHNSW.load(path, orc.L2, args.dim, mode=orc.SEQ, o3=True)
+            o = orc.OracleHNSW.load(path, orc.L2, dim, mode=orc.SEQ, o3=True)
         o.set_ef(chosen)
-        ncpu = min(args.cpu_queries, args.nq)
-        r = o.search(queries[:ncpu], args.k, n_threads=threads)
-        # cheap end-to-end sanity at full size: the GPU's answers for the sample against the
-        # oracle in the GPU's summation order (bit-exact parity lives in tests/)
+        ct = cores["cores"]
+        r = o.search(queries, k, n_threads=ct)              # one pass sizes the sample
+        passes = int(min(40, max(1, math.ceil(args.cpu_seconds / max(r["seconds"], 1e-6)))))
+        secs = [o.search(queries, k, n_threads=ct)["seconds"] for _ in range(passes)]
+        # cheap end-to-end sanity at full size: the GPU's answers against the oracle in the GPU's
+        # summation order (bit-exact parity lives in tests/)
         o.set_mode(orc.TREE64)
-        r2 = o.search(queries[:min(256, ncpu)], args.k, n_threads=threads)
-        same = bool(np.array_equal(r2["label"].astype(np.uint64), lab.cpu().numpy().view(np.uint64)[:len(r2["label"])]))
-        cpu = {"value": round(ncpu / r["seconds"], 1), "unit": "queries/s", "cores": threads, "kind": "port",
-               "sample": f"first {ncpu} queries of the batch, same graph, ef={chosen}, k={args.k}, "
-                         f"oracle -O3 in the reference's sequential-sum arithmetic, {threads} threads",
-               "recall_at_k": round(datasets.recall_at_k(r["label"].astype(np.uint64), gt[:ncpu]), 4),
-               "gpu_ids_equal_oracle_on_256": same}
+        r2 = o.search(queries, k, n_threads=ct)
+        same = bool(np.array_equal(r2["label"].astype(np.uint64), lab.cpu().numpy().view(np.uint64)) and
+                    np.array_equal(r2["dist"].view(np.uint32), dist_out.cpu().numpy().view(np.uint32)))
+        cpu = {"value": round(args.nq * passes / sum(secs), 1), "unit": "queries/s", "cores": ct, "kind": "port",
+               "sample": f"{passes} passes over the whole {args.nq}-query batch ({sum(secs):.2f} s wall, {sum(secs) * ct:.0f} core-seconds), "
+                         f"same graph, ef={chosen}, k={k}, oracle -O3 in the reference's sequential-sum arithmetic, {ct} threads = "
+                         f"the job's share of the host ({cores['host_cpus_visible']} CPUs visible; limits {cores['limits']})",
+               "host_cpus_visible": cores["host_cpus_visible"],
+               "recall_at_k": round(datasets.recall_at_k(r["label"].astype(np.uint64), gt), 4),
+               "gpu_ids_and_distances_equal_oracle_on_whole_batch": same}
+        del o
 
-    if rank == 0:
-        # HBM-side traffic per launch comes from a separate rocprofv3 --pmc FETCH_SIZE pass of this same
-        # command (counters cannot be read from inside the process); the committed summary is quoted
-        # when the workload is the one it was collected on.
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r1", "hnsw_c2_pmc_fetch_final.json")
-        if os.path.exists(pmc) and args.build == "host" and (args.n, args.dim, args.nq, args.k, args.M, chosen) == (1_000_000, 128, 10_000, 10, 16, 32):
+    bruteforce = None
+    if rank == 0 and world == 1 and not args.no_bruteforce:
+        del h, base
+        bruteforce = run_bruteforce(args, dev, cores, threads, standalone=False)
+
+    if rank != 0:
+        return None
+    # HBM-side traffic per launch comes from a separate rocprofv3 --pmc FETCH_SIZE pass of this same
+    # command (counters cannot be read from inside the process); the committed summary is quoted
+    # when the workload is the one it was collected on.
+    traffic, traffic_src = None, None
+    for rel in ("profiles/r2/hnsw_c2_pmc_fetch.json", "profiles/r1/hnsw_c2_pmc_fetch_final.json"):
+        pmc = os.path.join(ROOT, rel)
+        if os.path.exists(pmc) and args.build == "host" and (n, dim, args.nq, k, args.M, chosen) == (1_000_000, 128, 10_000, 10, 16, 32):
             with open(pmc) as f:
                 traffic = int(json.load(f)["traffic_bytes_per_launch"])
-            traffic_src = "profiles/r1/hnsw_c2_pmc_fetch_final.json (FETCH_SIZE KB x 1024 x 2, gfx950 correction)"
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        out = {
-            "metric": "queries/sec @ recall@10>=0.95 (1M x 128, k=10)",
-            "value": round(qps, 1),
-            "unit": "queries/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"HNSW {args.n}x{args.dim} fp32 SIFT-like synthetic, M={args.M}, "
-                                   f"efConstruction={args.efc}, {args.nq}-query batch per GPU, k={args.k}",
-                       "ef": chosen, "recall_at_10": round(recall, 4), "ef_sweep": sweep,
-                       "parallelism": "query-parallel replicas" if world > 1 else "single GPU",
-                       "mean_ndis": round(float(st[:, 0].mean()), 1), "mean_hops": round(float(st[:, 1].mean()), 1),
-                       "build_seconds_host" if args.build == "host" else "build_seconds_device": round(build_s, 1),
-                       "build_threads": threads},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": traffic_src, "kernel": "hnsw_search_kernel", "kernel_ms": round(kern_ms, 4),
-                         "algorithmic_bytes_per_launch": alg_bytes},
-            "cpu_baseline": cpu,
-        }
-        if sharded is not None:
-            out["sharded"] = sharded
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+            traffic_src = rel + " (FETCH_SIZE KB x 1024 x 2, gfx950 correction)"
+            break
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    out = {
+        "metric": "queries/sec @ recall@10>=0.95 (1M x 128, k=10)",
+        "value": round(qps, 1),
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"HNSW {n}x{dim} fp32 SIFT-like synthetic, M={args.M}, "
+                               f"efConstruction={args.efc}, {args.nq}-query batch per GPU, k={k}",
+                   "ef": chosen, "recall_at_10": round(recall, 4), "ef_sweep": sweep,
+                   "parallelism": "query-parallel replicas (no data-path collective); base-set sharding under 'sharded'"
+                   if world > 1 else "single GPU",
+                   "mean_ndis": round(float(st[:, 0].mean()), 1), "mean_hops": round(float(st[:, 1].mean()), 1),
+                   "build_seconds_host" if args.build == "host" else "build_seconds_device": round(build_s, 1),
+                   "build_threads": threads},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": traffic_src, "kernel": "hnsw_search_kernel", "kernel_ms": round(kern_ms, 4),
+                     "algorithmic_bytes_per_launch": alg_bytes},
+        "cpu_baseline": cpu,
+    }
+    if sharded is not None:
+        out["sharded"] = sharded
+    if bruteforce is not None:
+        out["bruteforce"] = bruteforce
+    return out
 
 
-def run_bruteforce(args) -> None:
+# ------------------------------------------------------------------------------------------------
+# configs[2]: exact brute force on the MFMA path
+# ------------------------------------------------------------------------------------------------
+
+def run_bruteforce(args, dev, cores, threads, standalone: bool):
     """BASELINE.json configs[2]: exact brute-force k-NN, 1M x 960 (GIST-like synthetic), 10 000-query
-    batches, k=10, on the MFMA candidate pass + exact re-rank.  One GPU (replicas for N > 1)."""
+    batches, k=10: f32 MFMA candidate pass + exact re-rank + certificate (bit-identical to the CPU
+    path) and bf16 MFMA candidate pass + exact re-rank.  standalone: its own JSON line (timing
+    `--precision`); else the "bruteforce" block of the default line (both precisions)."""
     import torch
 
     from vectordb_amd import datasets
     from vectordb_amd import index as vi
 
-    if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
-        raise SystemExit("--workload bruteforce is a single-GPU line")
-    dim = 960 if args.dim == 128 else args.dim
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
-    threads = max(1, min(args.build_threads or int(os.environ.get("OMP_NUM_THREADS", "0")) or 16, 16))
+    n = (args.n or 1_000_000) if standalone else 1_000_000
+    dim = (args.dim or 960) if standalone else 960
+    nq, k = args.nq, (args.k or 10)
     t0 = time.time()
     law = datasets.ClusteredLaw(dim, latent=64)
-    base = law.sample(args.n, seed=1)
-    queries = law.sample(args.nq, seed=2)
-    log(f"data {base.shape} + {queries.shape} in {time.time() - t0:.1f}s")
+    base = law.sample(n, seed=1)
+    queries = law.sample(nq, seed=2)
+    log(f"brute force: data {base.shape} + {queries.shape} in {time.time() - t0:.1f}s")
     t0 = time.time()
-    bf = vi.BruteforceSearch(vi.L2Space(dim), args.n)
+    bf = vi.BruteforceSearch(vi.L2Space(dim), n)
     bf.add_items(base)
-    bf.to_device(0)
-    log(f"uploaded + prepared (mean, centred f32/bf16 copies, norms) in {time.time() - t0:.1f}s")
+    bf.to_device(dev.index)
+    log(f"brute force: uploaded + prepared (mean, centred f32/bf16 copies, norms) in {time.time() - t0:.1f}s")
     dq = torch.from_numpy(queries).to(dev)
-    prec = {"fp32": vi.BF_FP32, "bf16": vi.BF_BF16, "bf16_rerank": vi.BF_BF16_RERANK}[args.precision]
 
     def timed(precision, steps, warmup):
         for _ in range(warmup):
-            bf.search_batch(dq, args.k, precision=precision)
+            bf.search_batch(dq, k, precision=precision)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for a, b in ev:
             a.record()
-            out = bf.search_batch(dq, args.k, precision=precision)
+            out = bf.search_batch(dq, k, precision=precision)
             b.record()
         torch.cuda.synchronize()
         return time.perf_counter() - t0, float(np.mean([a.elapsed_time(b) for a, b in ev])), out
 
+    flops = 2.0 * nq * n * dim
     # exact answer (f32 MFMA + exact re-rank + certificate) = ground truth for the bf16 recall
-    el32, ms32, (d32, l32) = timed(vi.BF_FP32, max(1, args.steps // 4), 1)
+    el32, ms32, (d32, l32) = timed(vi.BF_FP32, max(2, args.steps // 4), 1)
     truth = l32.cpu().numpy().view(np.uint64)
-    elapsed, ms, (dd, ll) = timed(prec, args.steps, args.warmup)
-    recall = datasets.recall_at_k(ll.cpu().numpy().view(np.uint64), truth)
-    flops = 2.0 * args.nq * args.n * dim
-    peak = 157.3 if args.precision == "fp32" else 2500.0   # MI355X_MICROARCH.md dense peaks, TFLOP/s
-    achieved = flops / (ms * 1e-3) / 1e12
-    log(f"fp32-exact {ms32:.1f} ms/batch ({flops / (ms32 * 1e-3) / 1e12:.1f} TFLOP/s of 157.3); "
-        f"{args.precision} {ms:.1f} ms/batch, recall@{args.k} vs exact {recall:.4f}")
+    prec_name = args.precision if standalone and args.precision != "fp32" else "bf16_rerank"
+    prec = {"bf16": vi.BF_BF16, "bf16_rerank": vi.BF_BF16_RERANK}[prec_name]
+    el16, ms16, (d16, l16) = timed(prec, args.steps, args.warmup)
+    recall = datasets.recall_at_k(l16.cpu().numpy().view(np.uint64), truth)
+    tf32, tf16 = flops / (ms32 * 1e-3) / 1e12, flops / (ms16 * 1e-3) / 1e12
+    log(f"brute force: fp32-exact {ms32:.1f} ms/batch ({tf32:.1f} TFLOP/s of {MFMA_PEAK_TF['fp32']}); "
+        f"{prec_name} {ms16:.2f} ms/batch ({tf16:.0f} TFLOP/s of {MFMA_PEAK_TF['bf16']}), recall@{k} vs exact {recall:.4f}")
 
-    cpu = None
+    cpu, bitexact = None, None
     if not args.no_cpu_baseline:
         from oracle import oracle as orc
         orc.build()
-        ncpu = min(2 * threads, args.nq)
-        ob = orc.OracleBruteforce(orc.L2, dim, args.n, mode=orc.SEQ, o3=True)
+        ct = cores["cores"]
+        ncpu = min(2 * ct, nq)
+        ob = orc.OracleBruteforce(orc.L2, dim, n, mode=orc.SEQ, o3=True)
         ob.add(base)
-        r = ob.search(queries[:ncpu], args.k, n_threads=threads)
-        ob.set_mode = None
-        ot = orc.OracleBruteforce(orc.L2, dim, args.n, mode=orc.TREE64, o3=True)
+        r = ob.search(queries[:ncpu], k, n_threads=ct)
+        del ob
+        ot = orc.OracleBruteforce(orc.L2, dim, n, mode=orc.TREE64, o3=True)
         ot.add(base)
-        r2 = ot.search(queries[:4], args.k, n_threads=4)
-        same = bool(np.array_equal(r2["label"].astype(np.uint64), truth[:4]) and
-                    np.array_equal(r2["dist"].view(np.uint32), d32.cpu().numpy()[:4].view(np.uint32)))
-        cpu = {"value": round(ncpu / r["seconds"], 2), "unit": "queries/s", "cores": threads, "kind": "port",
-               "sample": f"first {ncpu} queries, full {args.n}x{dim} scan, oracle -O3 sequential-sum arithmetic",
-               "gpu_fp32_bitexact_vs_oracle_on_4": same}
-    out = {
-        "metric": "queries/sec exact brute-force k-NN (1M x 960, k=10)",
-        "value": round(args.nq * args.steps / elapsed, 1), "unit": "queries/s", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision != "fp32" else "f32",
-        "data": "synthetic",
-        "config": {"workload": f"brute-force k-NN {args.n}x{dim} GIST-like synthetic, {args.nq}-query batch, k={args.k}, "
-                               f"precision {args.precision}", "recall_at_10_vs_exact": round(recall, 4),
-                   "fp32_exact_ms_per_batch": round(ms32, 2),
-                   "fp32_exact_tflops": round(flops / (ms32 * 1e-3) / 1e12, 1)},
-        "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4), "traffic": None, "kernel": "bf_gemm_filter (whole step timed: "
-                     "GEMM+filter, compaction, re-rank)", "kernel_ms": round(ms, 3), "algorithmic_flops_per_launch": flops},
-        "cpu_baseline": cpu,
+        nchk = min(ct, nq)
+        r2 = ot.search(queries[:nchk], k, n_threads=ct)
+        del ot
+        bitexact = bool(np.array_equal(r2["label"].astype(np.uint64), truth[:nchk]) and
+                        np.array_equal(r2["dist"].view(np.uint32), d32.cpu().numpy()[:nchk].view(np.uint32)))
+        cpu = {"value": round(ncpu / r["seconds"], 2), "unit": "queries/s", "cores": ct, "kind": "port",
+               "sample": f"first {ncpu} queries, full {n}x{dim} scan ({r['seconds']:.1f} s wall, {r['seconds'] * ct:.0f} core-seconds), "
+                         f"oracle -O3 sequential-sum arithmetic, {ct} threads", "host_cpus_visible": cores["host_cpus_visible"]}
+
+    def roof(name, ms, tf):
+        peak = MFMA_PEAK_TF["fp32" if name == "fp32" else "bf16"]
+        return {"ms_per_batch": round(ms, 3), "queries_per_s": round(nq / ms * 1e3, 1),
+                "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                             "traffic": None, "kernel": f"bf_gemm_filter<{'f32' if name == 'fp32' else 'bf16'}>",
+                             "kernel_ms": round(ms, 3),
+                             "kernel_ms_note": "HIP events around the whole step on its stream: prepare-queries, 14 slab launches of "
+                                               "GEMM+filter, compactions, exact re-rank (the GEMM's own time: profiles/)",
+                             "algorithmic_flops_per_launch": flops}}
+
+    if standalone:
+        sel = roof("fp32" if args.precision == "fp32" else prec_name, ms32 if args.precision == "fp32" else ms16,
+                   tf32 if args.precision == "fp32" else tf16)
+        steps = max(2, args.steps // 4) if args.precision == "fp32" else args.steps
+        el = el32 if args.precision == "fp32" else el16
+        return {"metric": "queries/sec exact brute-force k-NN (1M x 960, k=10)", "value": round(nq * steps / el, 1), "unit": "queries/s",
+                "n_gpus": 1, "steps": steps, "warmup": args.warmup, "ms_per_step": round(el / steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+                "config": {"workload": f"brute-force k-NN {n}x{dim} GIST-like synthetic, {nq}-query batch, k={k}, precision {args.precision}",
+                           "recall_at_10_vs_exact": round(recall, 4), "fp32_exact_ms_per_batch": round(ms32, 2),
+                           "fp32_exact_tflops": round(tf32, 1)},
+                "roofline": sel["roofline"], "cpu_baseline": cpu, "gpu_fp32_bitexact_vs_oracle": bitexact}
+    return {"workload": f"BASELINE.json configs[2]: exact brute-force k-NN {n}x{dim} GIST-like synthetic, {nq}-query batch, k={k}",
+            "fp32": roof("fp32", ms32, tf32), "bf16_rerank": dict(roof("bf16_rerank", ms16, tf16), recall_at_10_vs_exact=round(recall, 4)),
+            "gpu_fp32_bitexact_vs_oracle": bitexact, "cpu_baseline": cpu}
+
+
+# ------------------------------------------------------------------------------------------------
+# configs[3] / configs[4]: the configurations that exist only sharded
+# ------------------------------------------------------------------------------------------------
+
+def run_sharded_workload(args, dd, rank, local_rank, world, dev, cores, threads):
+    """c4: 10M x 96, rows L2-normalised, inner product, k=10.  c5: 100M x 128, L2, k=100.  The base set
+    is fixed and split over the ranks (contiguous global row ids; shard s's rows are drawn from the law
+    with seed 1000+s so that no rank materialises another rank's rows); every rank builds its shard's
+    graph on its GPU (vdb_index_add_batch_device), all ranks search the SAME 10 000-query batch, the
+    [nq,k] lists are all-gathered and merged on every rank.  Ground truth: exact brute force per shard
+    by the MFMA kernels, all-gathered and merged the same way.  One torchrun command per N gives the
+    1/2/4/8 curve: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N --workload c4`."""
+    import torch
+
+    from vectordb_amd import datasets, sharding
+    from vectordb_amd import index as vi
+
+    c4 = args.workload == "c4"
+    n = args.n or (10_000_000 if c4 else 100_000_000)
+    dim = args.dim or (96 if c4 else 128)
+    k = args.k or (10 if c4 else 100)
+    ef = args.ef or (48 if c4 else 200)
+    metric = vi.IP if c4 else vi.L2
+    law = datasets.ClusteredLaw(dim, latent=32, normalize=c4)
+    lo, hi = sharding.shard_range(n, world, rank)
+    t0 = time.time()
+    mine = law.sample(hi - lo, seed=1000 + rank)
+    labels = np.arange(lo, hi, dtype=np.uint64)
+    q = law.sample(args.nq, seed=2)
+    dq = torch.from_numpy(q).to(dev)
+    log(f"rank {rank}: rows [{lo}, {hi}) in {time.time() - t0:.1f}s")
+
+    space = vi.InnerProductSpace(dim) if c4 else vi.L2Space(dim)
+    t0 = time.time()
+    bf = vi.BruteforceSearch(space, hi - lo)
+    bf.add_items(mine, labels)
+    bf.to_device(local_rank)
+    td, tl = bf.search_batch(dq, k)
+    gd, gl = sharding.all_gather_results(td, tl)
+    _, truth = vi.merge_topk(gd, gl)
+    torch.cuda.synchronize()
+    truth = truth.cpu().numpy().view(np.uint64)
+    del bf
+    log(f"rank {rank}: exact ground truth over its shard + all-gather + merge in {time.time() - t0:.1f}s")
+
+    t0 = time.time()
+    hs = vi.HierarchicalNSW(space, hi - lo, args.M, args.efc, 100 + rank)
+    hs.add_items_device(mine, labels, n_threads=threads, device=local_rank)
+    build_s = dd.reduce(time.time() - t0)
+    del mine
+    hs.setefSearch(ef)
+    md, ml = sharding.sharded_search(hs, dq, k)
+    torch.cuda.synchronize()
+    recall = datasets.recall_at_k(ml.cpu().numpy().view(np.uint64), truth)
+    log(f"rank {rank}: shard graph on the device in {build_s:.1f}s ({hs.device_bytes() / 1e9:.2f} GB); ef={ef} recall@{k} {recall:.4f}")
+    wall, split, _ = timed_sharded_steps(sharding, hs, dq, k, args.steps, args.warmup, dd)
+    _, _, st = hs.search_batch(dq, k, stats=True)
+    st = st.cpu().numpy().view(np.uint32).astype(np.int64)
+    alg_bytes = int((st[:, 0] * 4 * dim + st[:, 1] * 4 * (2 * args.M + 1) + st[:, 2] * 4 * (args.M + 1)).sum()
+                    + args.nq * (4 * dim + k * 12))
+    achieved = alg_bytes / (dd.reduce(split["search"], "max") * 1e-3) / 1e9
+    ranks = dd.gather_objects({"rank": rank, "device": torch.cuda.current_device(), "rows": hi - lo})
+    if rank != 0:
+        return None
+    return {
+        "metric": f"queries/sec, sharded HNSW ({'10M x 96 inner product, k=10' if c4 else '100M x 128, k=100'})",
+        "value": round(args.nq * args.steps / wall, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[{3 if c4 else 4}]: HNSW {n}x{dim} {'normalised, 1 - <a,b>' if c4 else 'L2'}, "
+                               f"{world} shard(s), M={args.M}, efConstruction={args.efc}, {args.nq}-query batch, k={k}",
+                   "ef": ef, f"recall_at_{k}": round(recall, 4), "parallelism": f"base-set sharding over {world} rank(s), "
+                   "all-gather of the per-rank top-k lists + merge_topk on every rank", "ms_split_max_over_ranks": split,
+                   "shard_build_seconds_device": round(build_s, 1), "world_size": world,
+                   "backend": dd.d.get_backend() if world > 1 else None, "ranks": ranks},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "hnsw_search_kernel (rank 0's shard)",
+                     "kernel_ms": split["search"], "algorithmic_bytes_per_launch": alg_bytes},
+        "cpu_baseline": None,
     }
-    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

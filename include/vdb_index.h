@@ -85,7 +85,9 @@ int vdb_index_add_batch(vdb_index* idx, const float* vecs, const uint64_t* label
  * rounds of search (ef_construction) -> heuristic selection (:357-390) -> reverse links (:392-498) on
  * the GPU.  Levels, ids and labels are assigned exactly as vdb_index_add_batch does; the links are a
  * valid HNSW graph but not the sequential builder's graph (a batch has no insertion order).  Leaves
- * the index uploaded to `device`.  Needs ef_construction <= 508, M <= 32, no deleted elements. */
+ * the index uploaded to `device`.  Needs ef_construction <= 508, M <= 32, no deleted elements.
+ * On failure an index that was empty is empty again; for an append the new elements stay and the ones
+ * the device did not link are linked by the host builder before the error is returned. */
 int vdb_index_add_batch_device(vdb_index* idx, const float* vecs, const uint64_t* labels, size_t n, int n_threads,
                                int device);
 /* Summation order used by host-side build distances (default VDB_SUM_TREE64). */
@@ -93,6 +95,12 @@ int vdb_index_set_build_sum_order(vdb_index* idx, int order);
 
 /* setefSearch, hnsw_core.hpp:207-209 (default 10, :143/:655). */
 int vdb_index_set_ef(vdb_index* idx, size_t ef);
+/* Tuning switch of the device search (no reference counterpart; the reference's visited list is an O(n)
+ * array, visited_list_pool.hpp:36-58): whether queries that fill their LDS visited table carry on in a
+ * second-level table in HBM.  -1 = decided per ef from what earlier launches reported (default),
+ * 0 = never, 1 = always.  Results are identical in every mode.  The default is taken from the
+ * environment variable VDB_SPILL (0 / 1) once, when the index is created. */
+int vdb_index_set_spill_mode(vdb_index* idx, int mode);
 /* markDelete / unmarkDelete, hnsw_core.hpp:709-782. */
 int vdb_index_mark_delete(vdb_index* idx, uint64_t label);
 int vdb_index_unmark_delete(vdb_index* idx, uint64_t label);

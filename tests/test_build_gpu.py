@@ -83,3 +83,52 @@ def test_device_build_appends_to_an_existing_graph(orc):
     assert h.getElementCount() == n0 + n1
     assert h.checkIntegrity()[0] in (0, 4)
     assert _recall(h, x, q, 10, 64) >= 0.9
+
+
+@pytest.mark.parametrize("M", [24, 32])
+def test_device_build_wide_lists(orc, tmp_path, monkeypatch, M):
+    """maxM0 = 48 / 64: a full list plus its newcomers is up to 96 entries in build_reverse_kernel (two
+    per lane), and the heuristic scores against up to 64 kept neighbours.  Integrity, recall against the
+    host build, and bit-exact searches over the written-back graph."""
+    monkeypatch.setenv("VDB_BUILD_HOST_BASE", "64")
+    n, dim = 20000, 24
+    x = datasets.clustered(n, dim, 75)
+    q = datasets.clustered(300, dim, 76)
+    host = vi.HierarchicalNSW(vi.L2Space(dim), n, M, 100, 100)
+    host.add_items(x, n_threads=8)
+    host.to_device(0)
+    r_host = _recall(host, x, q, 10, 48)
+    dev = vi.HierarchicalNSW(vi.L2Space(dim), n, M, 100, 100)
+    dev.add_items_device(x, n_threads=8)
+    assert dev.checkIntegrity()[0] in (0, 4)
+    sizes = [len(dev.links(i, 0)) for i in range(0, n, 53)]
+    assert max(sizes) <= 2 * M and max(sizes) > 32 and np.mean(sizes) > M / 2     # lists beyond one lane's worth exist
+    r_dev = _recall(dev, x, q, 10, 48)
+    print(f"M={M}: recall@10 ef=48 host {r_host:.4f} device {r_dev:.4f}, mean list {np.mean(sizes):.1f}, max {max(sizes)}")
+    assert r_dev >= r_host - 0.02
+    path = str(tmp_path / "wide.bin")
+    dev.saveIndex(path)
+    o = orc.OracleHNSW.load(path, vi.L2, dim, mode=orc.TREE64)
+    dev.setefSearch(48)
+    o.set_ef(48)
+    d, l, st = dev.search_batch(q, 10, stats=True)
+    assert_same_results((d, l), o.search(q, 10), st)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 9])
+def test_device_build_of_a_handful_at_small_M(orc, tmp_path, n):
+    """M = 4 goes the way of an append; with so few elements usually none draws an upper level, so the
+    first one has to anchor the graph (entry point) before the device rounds run."""
+    dim = 8
+    x = datasets.uniform(n, dim, 77 + n)
+    h = vi.HierarchicalNSW(vi.L2Space(dim), 16, 4, 16, 100)
+    h.add_items_device(x, n_threads=1)
+    assert h.getElementCount() == n and h.entry < n and h.max_level == h.level_of(h.entry)
+    h.setefSearch(16)
+    d, l = h.search_batch(x, min(n, 3))
+    assert (l[:, 0] == np.arange(n)).all() and (d[:, 0] == 0).all()       # every element finds itself
+    path = str(tmp_path / "tiny.bin")
+    h.saveIndex(path)
+    o = orc.OracleHNSW.load(path, vi.L2, dim, mode=orc.TREE64)
+    o.set_ef(16)
+    assert_same_results((d, l), o.search(x, min(n, 3)))

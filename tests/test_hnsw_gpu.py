@@ -115,10 +115,10 @@ def test_spill_pool_grows_with_the_batch(orc, monkeypatch):
     h.to_device(0)
     h.setefSearch(256)
     o.set_ef(256)
-    monkeypatch.setenv("VDB_SPILL", "1")
+    h.set_spill_mode(1)
     h.search_batch(q[:32], 100)
     d1, l1, st1 = h.search_batch(q, 100, stats=True)
-    monkeypatch.setenv("VDB_SPILL", "0")
+    h.set_spill_mode(0)
     d0, l0, st0 = h.search_batch(q, 100, stats=True)
     np.testing.assert_array_equal(l1, l0)
     np.testing.assert_array_equal(d1.view(np.uint32), d0.view(np.uint32))
@@ -192,3 +192,69 @@ def test_device_pointer_api_and_errors(orc):
     h.markDelete(3)
     with pytest.raises(vi.VdbError):
         h.search_batch(q, 10)                      # stale device copy / deleted elements
+
+
+def test_hundreds_of_identical_vectors(orc):
+    """300 copies of one vector beside 2000 others: a query near the copies holds hundreds of keys at
+    exactly the bound's distance.  The reference expands every one of them.  Rows the device answers
+    equal the oracle's bit for bit; a query whose tie keys outgrow even the large configuration's array
+    is flagged (found = UINT32_MAX, NaN row), never answered from a truncated search."""
+    import torch
+    rng = np.random.default_rng(91)
+    x = datasets.uniform(2300, 16, 92)
+    x[500:800] = x[500]
+    q = np.concatenate([x[500:501] + 1e-3 * rng.standard_normal((40, 16)).astype(np.float32), datasets.uniform(60, 16, 93)])
+    h, o = build_pair(orc, x, vi.L2, 16, 64)
+    h.to_device(0)
+    for ef in (32, 100):
+        h.setefSearch(ef)
+        o.set_ef(ef)
+        d, l, st = (t.cpu().numpy() for t in h.search_batch(torch.from_numpy(q).cuda(), 10, stats=True))
+        ref = o.search(q, 10)
+        flagged = st.view(np.uint32)[:, 3] == 0xFFFFFFFF
+        ok = ~flagged
+        assert ok[40:].all()                                   # queries away from the copies are always answered
+        assert_same_results((d[ok], l[ok].view(np.uint64)), {key: v[ok] for key, v in ref.items() if key != "seconds"},
+                            st.view(np.uint32)[ok])
+        assert np.isnan(d[flagged]).all() and (l[flagged] == -1).all()
+        if flagged.any():
+            with pytest.raises(vi.VdbError) as e:
+                h.search_batch(q, 10)
+            assert e.value.code == 4
+
+
+def test_corrupt_graphs_are_refused(orc, tmp_path):
+    """A file whose entry point or links do not fit its own level structure must be an error at load /
+    upload (the reference: "Index seems to be corrupted"), not an out-of-bounds read in a kernel."""
+    import struct
+    x = datasets.uniform(3000, 8, 94)
+    h, _ = build_pair(orc, x, vi.L2, 8, 32)
+    path = str(tmp_path / "g.bin")
+    h.saveIndex(path)
+    raw = bytearray(open(path, "rb").read())
+    # header: 6 x size_t, int max_level, u32 entry, 5 x size_t (hnsw_core.hpp:555-568)
+    off_entry = 6 * 8 + 4
+    bad = bytearray(raw)
+    bad[off_entry:off_entry + 4] = struct.pack("<I", 3000)          # entry point outside the index
+    open(path, "wb").write(bad)
+    with pytest.raises(vi.VdbError):
+        vi.HierarchicalNSW(vi.L2Space(8), location=path)
+    # an upper-layer link to an element that has no upper layers
+    lvl0 = next(i for i in range(3000) if h.level_of(i) == 0)
+    hdr = 6 * 8 + 4 + 4 + 5 * 8
+    stride = struct.unpack_from("<Q", raw, 3 * 8)[0]
+    pos = hdr + 3000 * stride
+    patched = False
+    for i in range(3000):
+        nbytes = struct.unpack_from("<I", raw, pos)[0]
+        pos += 4
+        if nbytes and not patched and struct.unpack_from("<H", raw, pos)[0] > 0:
+            struct.pack_into("<I", raw, pos + 4, lvl0)              # first link of this node's layer-1 list
+            patched = True
+        pos += nbytes
+    assert patched
+    open(path, "wb").write(raw)
+    g = vi.HierarchicalNSW(vi.L2Space(8), location=path)
+    with pytest.raises(vi.VdbError) as e:
+        g.to_device(0)
+    assert "corrupted" in str(e.value)

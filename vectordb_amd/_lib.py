@@ -35,6 +35,7 @@ SIGNATURES = {
     "vdb_index_add_batch_device": (C.c_int, [_vp, _f32p, _u64p, C.c_size_t, C.c_int, C.c_int]),
     "vdb_index_set_build_sum_order": (C.c_int, [_vp, C.c_int]),
     "vdb_index_set_ef": (C.c_int, [_vp, C.c_size_t]),
+    "vdb_index_set_spill_mode": (C.c_int, [_vp, C.c_int]),
     "vdb_index_mark_delete": (C.c_int, [_vp, C.c_uint64]),
     "vdb_index_unmark_delete": (C.c_int, [_vp, C.c_uint64]),
     "vdb_index_resize": (C.c_int, [_vp, C.c_size_t]),

@@ -91,6 +91,9 @@ struct DevBuf {
         p = nullptr;
         bytes = 0;
     }
+    void reserve(size_t n) {  // grow only (the contents are not kept)
+        if (bytes < n || !p) alloc(n);
+    }
     ~DevBuf() { release(); }
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
@@ -109,12 +112,36 @@ struct SearchScratch {
     // read (without synchronising) before the next launch to size the visited set (see search_device)
     uint32_t* report = nullptr;
     uint32_t report_ef = 0;
+    // recorded behind the launch that writes `report`; the words are read (and the next observation
+    // armed) only once it has completed, so what a launch adapts to never depends on timing
+    hipEvent_t report_done = nullptr;
+    bool report_pending = false;
     ~SearchScratch() {
         if (report) (void)hipHostFree(report);
+        if (report_done) (void)hipEventDestroy(report_done);
     }
     size_t redo_cap = 0;
     uint32_t bitmap_words = 0;
 };
+
+// Device staging of the host-pointer entry points, kept per index (grow only) instead of a
+// hipMalloc/hipFree of four buffers per call; `lock` serialises those (synchronous) calls.
+struct HostStage {
+    std::mutex lock;
+    DevBuf q, dist, label, stats, filter;
+    void release() {
+        q.release();
+        dist.release();
+        label.release();
+        stats.release();
+        filter.release();
+    }
+};
+
+int spill_mode_from_env() {  // VDB_SPILL=0 / 1 (tests): never / always hand out spill tables; unset: adaptive
+    const char* e = std::getenv("VDB_SPILL");
+    return e ? (e[0] == '1' ? 1 : 0) : -1;
+}
 
 }  // namespace
 
@@ -128,8 +155,10 @@ struct vdb_index {
     DevBuf live;  // bit i = element i is not deleted; allocated only when the upload saw deleted elements
     std::map<uint32_t, uint32_t> hbits_bias;  // per ef: extra log2 of the visited-set size (guarded by scratch_lock)
     std::set<uint32_t> spill_ef;              // the ef values at which a launch had queries outgrow the LDS table (same lock)
+    int spill_mode = spill_mode_from_env();   // -1 adaptive, 0 never, 1 always (read once, at creation)
     std::mutex scratch_lock;
     std::map<hipStream_t, std::unique_ptr<SearchScratch>> scratch;
+    HostStage stage;
 
     size_t device_bytes() const {
         return device < 0 ? 0 : vecs.bytes + links0.bytes + upper_row.bytes + upper_links.bytes + labels.bytes + live.bytes;
@@ -140,6 +169,7 @@ struct vdb_index {
             DeviceGuard g(device);
             (void)hipDeviceSynchronize();
             scratch.clear();
+            stage.release();
             vecs.release();
             links0.release();
             upper_row.release();
@@ -161,6 +191,7 @@ struct vdb_bruteforce {
     uint32_t n = 0, vstride = 0, kp64 = 0;
     std::mutex scratch_lock;
     std::map<hipStream_t, std::unique_ptr<DevBuf>> scratch;
+    HostStage stage;
 
     void drop_device() {
         if (device < 0) return;
@@ -168,6 +199,7 @@ struct vdb_bruteforce {
             DeviceGuard g(device);
             (void)hipDeviceSynchronize();
             scratch.clear();
+            stage.release();
             vecs.release();
             labels.release();
             xc.release();
@@ -272,14 +304,20 @@ void upload(vdb_index* idx, int device) {
     idx->upper_links.alloc(rows * (size_t)ustride * 4);
     idx->labels.alloc(n * 8);
 
-    auto check_list = [&](const uint32_t* ids, unsigned cnt, size_t cap, size_t self) {
+    // What the kernels assume of a graph, checked here so that a corrupt or foreign file is an error
+    // (the reference's "Index seems to be corrupted", hnsw_core.hpp:1129) and never an out-of-bounds read:
+    // the entry point exists and has max_level levels; every link of layer lv names an existing element
+    // that HAS a layer lv; no list names an element twice.
+    if (n != 0 && (h.entry >= n || h.max_level < 0 || h.levels[h.entry] != h.max_level))
+        throw std::runtime_error("Index seems to be corrupted: bad entry point or maximum level");
+    auto check_list = [&](const uint32_t* ids, unsigned cnt, size_t cap, int lv) {
         if (cnt > cap) throw std::runtime_error("Index seems to be corrupted: list count above its capacity");
         for (unsigned a = 0; a < cnt; ++a) {
             if (ids[a] >= n) throw std::runtime_error("Index seems to be corrupted: link to a non-existent element");
+            if (h.levels[ids[a]] < lv) throw std::runtime_error("Index seems to be corrupted: link on a level the target does not have");
             for (unsigned b = 0; b < a; ++b)
                 if (ids[a] == ids[b]) throw std::runtime_error("Index seems to be corrupted: duplicate link in a list");
         }
-        (void)self;
     };
 
     const size_t chunk = 1 << 16;
@@ -311,7 +349,7 @@ void upload(vdb_index* idx, int device) {
                     std::fill(dv + h.dim, dv + vstride, 0.f);
                     const uint32_t* l0 = h.list0(id);
                     const unsigned c0 = HostIndex::list_count(l0);
-                    check_list(l0 + 1, c0, h.maxM0, id);
+                    check_list(l0 + 1, c0, h.maxM0, 0);
                     uint32_t* dl = sl.data() + i * l0stride;
                     std::copy(l0 + 1, l0 + 1 + c0, dl);
                     std::fill(dl + c0, dl + l0stride, kNoId);
@@ -319,7 +357,7 @@ void upload(vdb_index* idx, int device) {
                     for (int lv = 1; lv <= h.levels[id]; ++lv) {
                         const uint32_t* ul = h.list_at(id, lv);
                         const unsigned cu = HostIndex::list_count(ul);
-                        check_list(ul + 1, cu, h.maxM, id);
+                        check_list(ul + 1, cu, h.maxM, lv);
                         uint32_t* du = su.data() + ((size_t)up_row[id] + (size_t)(lv - 1) - urow_lo) * ustride;
                         std::copy(ul + 1, ul + 1 + cu, du);
                     }
@@ -439,26 +477,36 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
     if (!s.report) {
         VDB_HIP(hipHostMalloc((void**)&s.report, 8, hipHostMallocMapped));
         s.report[0] = s.report[1] = 0;
+        VDB_HIP(hipEventCreateWithFlags(&s.report_done, hipEventDisableTiming));
     }
-    {
-        const uint32_t redone = ((volatile uint32_t*)s.report)[0], of = ((volatile uint32_t*)s.report)[1];
-        if (of != 0 && s.report_ef != 0) {
-            if (redone != 0) idx->spill_ef.insert(s.report_ef);
-            if ((uint64_t)redone * 50u > of) {
-                uint32_t& b = idx->hbits_bias[s.report_ef];
-                if (b < 3) b += 1;
+    // One observation per launch, taken only when the launch that wrote the words has completed
+    // (its event); while it is still running the words are left alone and this launch does not
+    // ask for a report, so nothing is read or zeroed under a kernel that may be writing it.
+    bool arm_report = true;
+    if (s.report_pending) {
+        if (hipEventQuery(s.report_done) == hipSuccess) {
+            const uint32_t redone = s.report[0], of = s.report[1];
+            if (of != 0 && s.report_ef != 0) {
+                if (redone != 0) idx->spill_ef.insert(s.report_ef);
+                if ((uint64_t)redone * 50u > of) {
+                    uint32_t& b = idx->hbits_bias[s.report_ef];
+                    if (b < 3) b += 1;
+                }
             }
-            ((volatile uint32_t*)s.report)[1] = 0;  // one observation per launch
+            s.report[0] = s.report[1] = 0;
+            s.report_pending = false;
+        } else {
+            (void)hipGetLastError();  // hipErrorNotReady is not an error here
+            arm_report = false;
         }
     }
     HnswSearchWork work;
     work.redo = (uint32_t*)s.redo.p;
     // Spill tables (hnsw_search.hip, LdsVisited) go to the launches at an ef at which an earlier launch
     // had queries outgrow the LDS table: the kernel variant that can spill is 1-5 % slower for the
-    // searches that never do.  VDB_SPILL=0 / 1 (tests) = never / always.
+    // searches that never do.  vdb_index_set_spill_mode / VDB_SPILL at creation (tests) = never / always.
     {
-        const char* force = std::getenv("VDB_SPILL");
-        const bool on = force ? force[0] == '1' : idx->spill_ef.count((uint32_t)ef) != 0;
+        const bool on = idx->spill_mode >= 0 ? idx->spill_mode == 1 : idx->spill_ef.count((uint32_t)ef) != 0;
         work.spill = on ? (uint32_t*)s.spill.p : nullptr;
         work.spill_tables = s.spill_tables;
     }
@@ -468,17 +516,21 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
         if (!s.ghash.p) s.ghash.alloc(((size_t)kGlobalHashBlocks << kGlobalHashBits) * 4);
         work.ghash = (uint32_t*)s.ghash.p;
     }
-    work.report = s.report;
+    work.report = arm_report ? s.report : nullptr;
     {
         auto it = idx->hbits_bias.find((uint32_t)ef);
         work.hbits_bias = it == idx->hbits_bias.end() ? 0u : it->second;
     }
-    s.report_ef = (uint32_t)ef;
     if (fail_word) *fail_word = work.redo + 1;
     std::string err;
     const int rc = launch_hnsw_search(idx->graph, d_queries, (uint32_t)nq, (uint32_t)k, (uint32_t)ef, allow, d_out_dist,
                                       d_out_label, d_out_stats, work, stream, &err);
     if (rc != 0) return set_error(rc, err);
+    if (arm_report) {
+        s.report_ef = (uint32_t)ef;
+        VDB_HIP(hipEventRecord(s.report_done, stream));
+        s.report_pending = true;
+    }
     return (int)VDB_OK;
 }
 
@@ -490,31 +542,34 @@ int search_host(vdb_index* idx, const float* queries, size_t nq, size_t k, const
     if (k == 0) throw std::invalid_argument("k must be > 0");
     DeviceGuard guard(idx->device);
     const size_t dim = idx->host->dim;
-    DevBuf dq, dd, dl, ds, df;
-    dq.alloc(nq * dim * 4);
-    dd.alloc(nq * k * 4);
-    dl.alloc(nq * k * 8);
-    if (out_stats) ds.alloc(nq * 16);
-    VDB_HIP(hipMemcpy(dq.p, queries, nq * dim * 4, hipMemcpyHostToDevice));
+    HostStage& st = idx->stage;
+    std::unique_lock<std::mutex> stage_guard(st.lock);
+    st.q.reserve(nq * dim * 4);
+    st.dist.reserve(nq * k * 4);
+    st.label.reserve(nq * k * 8);
+    if (out_stats) st.stats.reserve(nq * 16);
+    VDB_HIP(hipMemcpy(st.q.p, queries, nq * dim * 4, hipMemcpyHostToDevice));
     if (filter) {
         const size_t words = ((size_t)idx->graph.n + 31) / 32;
-        df.alloc(std::max<size_t>(words, 1) * 4);
-        VDB_HIP(hipMemcpy(df.p, filter, words * 4, hipMemcpyHostToDevice));
+        st.filter.reserve(std::max<size_t>(words, 1) * 4);
+        VDB_HIP(hipMemcpy(st.filter.p, filter, words * 4, hipMemcpyHostToDevice));
     }
     uint32_t* fail_word = nullptr;
-    const int rc = search_device(idx, (const float*)dq.p, nq, k, filter ? (const uint32_t*)df.p : nullptr, (float*)dd.p,
-                                 (uint64_t*)dl.p, out_stats ? (uint32_t*)ds.p : nullptr, nullptr, &fail_word);
+    const int rc = search_device(idx, (const float*)st.q.p, nq, k, filter ? (const uint32_t*)st.filter.p : nullptr,
+                                 (float*)st.dist.p, (uint64_t*)st.label.p, out_stats ? (uint32_t*)st.stats.p : nullptr, nullptr,
+                                 &fail_word);
     if (rc != VDB_OK) return rc;
     VDB_HIP(hipStreamSynchronize(nullptr));
     uint32_t failed = 0;
     if (fail_word) VDB_HIP(hipMemcpy(&failed, fail_word, 4, hipMemcpyDeviceToHost));
-    VDB_HIP(hipMemcpy(out_dist, dd.p, nq * k * 4, hipMemcpyDeviceToHost));
-    VDB_HIP(hipMemcpy(out_label, dl.p, nq * k * 8, hipMemcpyDeviceToHost));
-    if (out_stats) VDB_HIP(hipMemcpy(out_stats, ds.p, nq * 16, hipMemcpyDeviceToHost));
+    VDB_HIP(hipMemcpy(out_dist, st.dist.p, nq * k * 4, hipMemcpyDeviceToHost));
+    VDB_HIP(hipMemcpy(out_label, st.label.p, nq * k * 8, hipMemcpyDeviceToHost));
+    if (out_stats) VDB_HIP(hipMemcpy(out_stats, st.stats.p, nq * 16, hipMemcpyDeviceToHost));
     if (failed)
         throw Unsupported(std::to_string(failed) +
                           " queries hold more live candidates outside the result set than the device search keeps "
-                          "(a filter that rejects almost every element): their rows are NaN / UINT64_MAX");
+                          "(a filter that rejects almost every element, or hundreds of base vectors at exactly the "
+                          "same distance): their rows are NaN / UINT64_MAX");
     return (int)VDB_OK;
 }
 
@@ -650,27 +705,41 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
     if (!sc->report) {
         VDB_HIP(hipHostMalloc((void**)&sc->report, 8, hipHostMallocMapped));
         sc->report[0] = sc->report[1] = 0;
+        VDB_HIP(hipEventCreateWithFlags(&sc->report_done, hipEventDisableTiming));
+    }
+    if (sc->report_pending) {  // a query launch's observation still in flight: let it land, then drop it
+        VDB_HIP(hipEventSynchronize(sc->report_done));
+        sc->report[0] = sc->report[1] = 0;
+        sc->report_pending = false;
     }
     sc->report_ef = 0;  // (not an observation of a query launch)
     if (efc > 124) {
         if (!sc->ghash.p) sc->ghash.alloc(((size_t)kGlobalHashBlocks << kGlobalHashBits) * 4);
         work.ghash = (uint32_t*)sc->ghash.p;
     }
-    work.report = sc->report;
     std::string err;
     size_t done = 0, round = 0;
     while (done < dev_ids.size()) {
-        {
-            const uint32_t redone = ((volatile uint32_t*)sc->report)[0], of = ((volatile uint32_t*)sc->report)[1];
-            if (of != 0) {
-                if (redone != 0) {  // as in search_device
-                    work.spill = (uint32_t*)sc->spill.p;
-                    work.spill_tables = sc->spill_tables;
+        // as in search_device: an observation is read only behind the event of the round that wrote it
+        bool arm_report = true;
+        if (sc->report_pending) {
+            if (hipEventQuery(sc->report_done) == hipSuccess) {
+                const uint32_t redone = sc->report[0], of = sc->report[1];
+                if (of != 0) {
+                    if (redone != 0) {
+                        work.spill = (uint32_t*)sc->spill.p;
+                        work.spill_tables = sc->spill_tables;
+                    }
+                    if ((uint64_t)redone * 50u > of && work.hbits_bias < 3) work.hbits_bias += 1;
                 }
-                if ((uint64_t)redone * 50u > of && work.hbits_bias < 3) work.hbits_bias += 1;
-                ((volatile uint32_t*)sc->report)[1] = 0;
+                sc->report[0] = sc->report[1] = 0;
+                sc->report_pending = false;
+            } else {
+                (void)hipGetLastError();
+                arm_report = false;
             }
         }
+        work.report = arm_report ? sc->report : nullptr;
         // a batch is searched against the graph WITHOUT its own members: keep it a fraction of it
         const size_t nb = std::min<size_t>(std::min<size_t>(max_batch, std::max<size_t>(linked / 4, 8)), dev_ids.size() - done);
         const uint32_t* bid = (const uint32_t*)ids.p + done;
@@ -678,6 +747,10 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
             throw DeviceError("gather kernel launch failed");
         int rc = launch_hnsw_search(gb, (const float*)q.p, (uint32_t)nb, efc, efc, nullptr, (float*)cd.p, (uint64_t*)cl.p, nullptr,
                                     work, stream, &err);
+        if (rc == 0 && arm_report) {
+            VDB_HIP(hipEventRecord(sc->report_done, stream));
+            sc->report_pending = true;
+        }
         if (rc == 0)
             rc = launch_build_round(gb, links0, (const uint64_t*)cl.p, (const float*)cd.p, bid, (uint32_t)nb, efc, M, maxM0, w,
                                     stream, &err);
@@ -692,7 +765,8 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
         }
     }
     VDB_HIP(hipStreamSynchronize(stream));
-    sc->report[1] = 0;
+    sc->report[0] = sc->report[1] = 0;
+    sc->report_pending = false;
     tr.lap("device rounds (layer 0)", dev_ids.size());
     // the device lists are the graph now: write them back in the reference's layout (:259-261, :283-285)
     const uint32_t ls = g0.l0stride;
@@ -799,15 +873,25 @@ int vdb_index_add_batch_device(vdb_index* idx, const float* vecs, const uint64_t
         if (h.ef_construction > kMaxEf) throw Unsupported("device graph build needs ef_construction <= 508");
         if (round_up(h.maxM0, 32) > kMaxL0Stride) throw Unsupported("M above 32 is not supported by the device path");
         if (round_up(h.dim, 32) > kMaxVecStride) throw Unsupported("dim above 1024 is not supported by the device path");
-        {  // nothing is stored unless the device is there: a failed call leaves the index as it was
+        {  // nothing is stored unless the device is there
             int ndev = 0;
             if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw DeviceError("no HIP device visible");
             if (device < 0 || device >= ndev) throw std::invalid_argument("device ordinal out of range");
             if (h.count + n > h.capacity) throw std::runtime_error("The number of elements exceeds the specified limit");
         }
         BuildTrace tr;
+        const uint64_t rng0 = h.rng_state();
         const size_t base = h.append_unlinked(vecs, labels, n);
         tr.lap("rows stored", n);
+        // A failure from here on must not leave stored elements that no search can reach.  A graph that
+        // was empty goes back to empty (rows, labels, levels and the level generator as before the call);
+        // for an append the host graph is intact until the rounds' write-back, so the elements the device
+        // did not link are linked by the host builder (the reference algorithm) and the error is returned.
+        auto undo_new_graph = [&] {
+            idx->drop_device();
+            h.truncate_to_empty();
+            h.set_rng_state(rng0);
+        };
         // A new graph: every layer through the device rounds (small sub-graphs on the host).  Not for
         // M < 8: there a quarter or more of the elements have upper levels, and their layer-0 lists,
         // seeded from layer 1 and filled by reverse links only, cost recall (0.935 against 0.981 for
@@ -815,21 +899,47 @@ int vdb_index_add_batch_device(vdb_index* idx, const float* vecs, const uint64_t
         if (base == 0 && h.M >= 8) {
             size_t host_base = 8192;
             if (const char* e = std::getenv("VDB_BUILD_HOST_BASE")) host_base = (size_t)std::max(64l, std::atol(e));
-            build_empty_graph(idx, n_threads, device, host_base, tr);
-            if (idx->device < 0 || idx->device_version != h.version) upload(idx, device);
+            try {
+                build_empty_graph(idx, n_threads, device, host_base, tr);
+                if (idx->device < 0 || idx->device_version != h.version) upload(idx, device);
+            } catch (...) {
+                undo_new_graph();
+                throw;
+            }
             return (int)VDB_OK;
         }
         // appending to an existing graph: the host builder (reference algorithm) inserts the elements
         // that have upper levels, the others go into layer 0 by the device rounds
         std::vector<uint32_t> host_ids, dev_ids;
         for (size_t i = 0; i < n; ++i) (h.levels[base + i] > 0 ? host_ids : dev_ids).push_back((uint32_t)(base + i));
-        h.link_elements(host_ids.data(), host_ids.size(), n_threads);
-        tr.lap("host-linked elements with upper levels", host_ids.size());
-        if (dev_ids.empty()) {
-            upload(idx, device);
-            return (int)VDB_OK;
+        if (h.entry == kNoId && host_ids.empty()) {  // an empty graph and no element drew an upper level:
+            host_ids.push_back(dev_ids.front());     // the first one anchors it (sets the entry point, :1099-1102)
+            dev_ids.erase(dev_ids.begin());
         }
-        device_rounds(idx, dev_ids, base + host_ids.size(), device, tr);
+        try {
+            h.link_elements(host_ids.data(), host_ids.size(), n_threads);
+            tr.lap("host-linked elements with upper levels", host_ids.size());
+            if (dev_ids.empty()) {
+                upload(idx, device);
+                return (int)VDB_OK;
+            }
+        } catch (...) {
+            if (base == 0) undo_new_graph();
+            throw;
+        }
+        try {
+            device_rounds(idx, dev_ids, base + host_ids.size(), device, tr);
+        } catch (const std::exception& e) {
+            if (base == 0) {
+                undo_new_graph();
+                throw;
+            }
+            idx->drop_device();
+            const std::string why = e.what();
+            h.link_elements(dev_ids.data(), dev_ids.size(), n_threads);
+            throw DeviceError(why + " (the device rounds failed; the " + std::to_string(dev_ids.size()) +
+                              " elements they were to link were linked by the host builder instead)");
+        }
         return (int)VDB_OK;
     });
 }
@@ -847,6 +957,16 @@ int vdb_index_set_ef(vdb_index* idx, size_t ef) {
     return guarded([&] {
         if (!idx) throw std::invalid_argument("null index");
         idx->host->ef_search = ef;
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_index_set_spill_mode(vdb_index* idx, int mode) {
+    return guarded([&] {
+        if (!idx) throw std::invalid_argument("null index");
+        if (mode < -1 || mode > 1) throw std::invalid_argument("spill mode must be -1 (adaptive), 0 (never) or 1 (always)");
+        std::unique_lock<std::mutex> lock(idx->scratch_lock);
+        idx->spill_mode = mode;
         return (int)VDB_OK;
     });
 }
@@ -1078,17 +1198,18 @@ int vdb_bf_search_batch(const vdb_bruteforce* bf, const float* queries, size_t n
         if (k == 0) throw std::invalid_argument("k must be > 0");
         DeviceGuard guard(bf->device);
         const size_t dim = bf->host->dim;
-        DevBuf dq, dd, dl;
-        dq.alloc(nq * dim * 4);
-        dd.alloc(nq * k * 4);
-        dl.alloc(nq * k * 8);
-        VDB_HIP(hipMemcpy(dq.p, queries, nq * dim * 4, hipMemcpyHostToDevice));
-        const int rc = vdb_bf_search_batch_device(bf, (const float*)dq.p, nq, k, precision, (float*)dd.p,
-                                                  (uint64_t*)dl.p, nullptr);
+        HostStage& st = const_cast<vdb_bruteforce*>(bf)->stage;
+        std::unique_lock<std::mutex> stage_guard(st.lock);
+        st.q.reserve(nq * dim * 4);
+        st.dist.reserve(nq * k * 4);
+        st.label.reserve(nq * k * 8);
+        VDB_HIP(hipMemcpy(st.q.p, queries, nq * dim * 4, hipMemcpyHostToDevice));
+        const int rc = vdb_bf_search_batch_device(bf, (const float*)st.q.p, nq, k, precision, (float*)st.dist.p,
+                                                  (uint64_t*)st.label.p, nullptr);
         if (rc != VDB_OK) return rc;
         VDB_HIP(hipStreamSynchronize(nullptr));
-        VDB_HIP(hipMemcpy(out_dist, dd.p, nq * k * 4, hipMemcpyDeviceToHost));
-        VDB_HIP(hipMemcpy(out_label, dl.p, nq * k * 8, hipMemcpyDeviceToHost));
+        VDB_HIP(hipMemcpy(out_dist, st.dist.p, nq * k * 4, hipMemcpyDeviceToHost));
+        VDB_HIP(hipMemcpy(out_label, st.label.p, nq * k * 8, hipMemcpyDeviceToHost));
         return (int)VDB_OK;
     });
 }

@@ -135,10 +135,13 @@ struct ReverseArgs {
 };
 
 // One wave per run of equal keys (the block at the head of the run does the work).
+// The pool of a full list is the old list (up to maxM0 <= 64 ids) plus up to 32 newcomers: at most
+// 96 entries, kept two per lane (entry i in lane i % 64, register i / 64).
 template <int NCH, int GPB, bool IS_L2>
 __global__ __launch_bounds__(64) void build_reverse_kernel(ReverseArgs a) {
-    __shared__ uint32_t c_id[64], c_d[64];
-    __shared__ uint64_t s_key[64];
+    constexpr uint32_t kPoolCap = 128;
+    __shared__ uint32_t c_id[kPoolCap], c_d[kPoolCap];
+    __shared__ uint64_t s_key[kPoolCap];
     const int lane = lane_id();
     const uint32_t i = blockIdx.x;
     const uint32_t nb = a.key[i];
@@ -157,33 +160,51 @@ __global__ __launch_bounds__(64) void build_reverse_kernel(ReverseArgs a) {
         return;
     }
     // full: the heuristic over old list + newcomers, seen from nb (:428-468)
-    const uint32_t shifted = bpermute(add, (lane - (int)c) & 63);
-    const uint32_t pool = (uint32_t)lane < c ? cur : ((uint32_t)lane < c + t ? shifted : kNoId);
-    const uint32_t n_pool = c + t;  // <= 64
+    const uint32_t n_pool = c + t;  // c <= 64, t <= 32
+    const uint32_t sh0 = bpermute(add, (lane - (int)c) & 63);       // entry lane      = add[lane - c]
+    const uint32_t sh1 = bpermute(add, (lane + 64 - (int)c) & 63);  // entry 64 + lane = add[64 + lane - c]
+    const uint32_t pool0 = (uint32_t)lane < c ? cur : ((uint32_t)lane < n_pool ? sh0 : kNoId);
+    const uint32_t pool1 = 64u + (uint32_t)lane < n_pool ? sh1 : kNoId;
     f32x4 qn[NCH];
     load_row_as_query<NCH>(a.g, nb, lane, qn);
-    uint32_t d = kEmptyWord;
+    uint32_t d0 = kEmptyWord, d1 = kEmptyWord;  // ordered distances of pool0 / pool1 to nb
     {
         const uint32_t m0 = n_pool < 32u ? n_pool : 32u;
-        const uint32_t d0 = score_nodes<NCH, GPB, IS_L2>(a.g, qn, pool, m0, lane);
-        if ((uint32_t)lane < m0) d = d0;
+        const uint32_t r0 = score_nodes<NCH, GPB, IS_L2>(a.g, qn, pool0, m0, lane);
+        if ((uint32_t)lane < m0) d0 = r0;
         if (n_pool > 32u) {
-            const uint32_t ids_hi = bpermute(pool, (lane + 32) & 63);
-            const uint32_t d1 = score_nodes<NCH, GPB, IS_L2>(a.g, qn, ids_hi, n_pool - 32u, lane);
-            const uint32_t d1s = bpermute(d1, (lane - 32) & 63);
-            if ((uint32_t)lane >= 32u && (uint32_t)lane < n_pool) d = d1s;
+            const uint32_t m1 = n_pool - 32u < 32u ? n_pool - 32u : 32u;
+            const uint32_t ids_hi = bpermute(pool0, (lane + 32) & 63);
+            const uint32_t r1 = score_nodes<NCH, GPB, IS_L2>(a.g, qn, ids_hi, m1, lane);
+            const uint32_t r1s = bpermute(r1, (lane - 32) & 63);
+            if ((uint32_t)lane >= 32u && (uint32_t)lane < 32u + m1) d0 = r1s;
+        }
+        if (n_pool > 64u) {
+            const uint32_t m2 = n_pool - 64u;
+            const uint32_t r2 = score_nodes<NCH, GPB, IS_L2>(a.g, qn, pool1, m2, lane);
+            if ((uint32_t)lane < m2) d1 = r2;
         }
     }
     // sort the pool closest first (rank by counting; equal distances: larger id first, :363-366)
-    const uint64_t k = ((uint64_t)d << 32) | (uint32_t)~pool;
-    s_key[lane] = (uint32_t)lane < n_pool ? k : ~0ull;
+    const uint64_t k0 = ((uint64_t)d0 << 32) | (uint32_t)~pool0;
+    const uint64_t k1 = ((uint64_t)d1 << 32) | (uint32_t)~pool1;
+    s_key[lane] = (uint32_t)lane < n_pool ? k0 : ~0ull;
+    s_key[64 + lane] = 64u + (uint32_t)lane < n_pool ? k1 : ~0ull;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    uint32_t rank = 0;
-    for (uint32_t j = 0; j < n_pool; ++j) rank += s_key[j] < k ? 1u : 0u;
+    uint32_t rank0 = 0, rank1 = 0;
+    for (uint32_t j = 0; j < n_pool; ++j) {
+        const uint64_t o = s_key[j];
+        rank0 += o < k0 ? 1u : 0u;
+        rank1 += o < k1 ? 1u : 0u;
+    }
     if ((uint32_t)lane < n_pool) {
-        c_id[rank] = pool;
-        c_d[rank] = d;
+        c_id[rank0] = pool0;
+        c_d[rank0] = d0;
+    }
+    if (64u + (uint32_t)lane < n_pool) {
+        c_id[rank1] = pool1;
+        c_d[rank1] = d1;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -225,7 +246,7 @@ int launch_build_round(const DevGraph& g, uint32_t* d_links0, const uint64_t* d_
                        const uint32_t* d_new_ids, uint32_t nb, uint32_t efc, uint32_t M, uint32_t maxM0, const BuildWork& w,
                        hipStream_t stream, std::string* err) {
     if (nb == 0) return 0;
-    if (efc > kMaxEf || M > 64 || g.l0stride > kMaxL0Stride || maxM0 > g.l0stride) {
+    if (efc > kMaxEf || M > 32 || maxM0 > 64 || g.l0stride > kMaxL0Stride || maxM0 > g.l0stride) {
         if (err) *err = "device graph build: ef_construction above 508 or M above 32 is not supported";
         return 4;
     }

@@ -329,6 +329,7 @@ struct SearchArgs {
     uint32_t* bitmaps;     // large configuration: [gridDim.x][bitmap_words]
     uint32_t* report;      // nullable, host-mapped: [0] = queries the fast configuration gave up on, [1] = nq
     uint32_t bitmap_words;
+    uint32_t large_blocks; // grid of the large configuration (host side only)
 };
 
 // FILT = the non-bare searchBaseLayerST (hnsw_core.hpp:1141-1148 with deleted elements or a filter):
@@ -336,7 +337,8 @@ struct SearchArgs {
 // the best candidate is beyond the ef-th RESULT (:316).  Restated on the one sorted array: see
 // KeyArray (S == 2) and DESIGN.md "Filtered search".
 // VIS: where the visited set lives - 0 hash in LDS (one query per block), 1 hash in HBM (persistent
-// blocks walking the batch), 2 exact bitmap in HBM = the large configuration over the re-run list,
+// blocks walking the batch), 2 exact bitmap in HBM = the large configuration over the re-run list
+// (exact unless the key array itself overflows, which is reported per query: found = UINT32_MAX),
 // 3 = 0 with a second-level table in HBM for the queries that fill the LDS one (LdsVisited).
 template <int NCH, int GPB, int R, int VIS, bool IS_L2, bool FILT>
 __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
@@ -556,9 +558,10 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
                     a.redo[kRedoHeader + slot] = qi;
                 }
                 continue;
-            } else if constexpr (FILT) {
-                // more live candidates that are not results than the largest array holds (a filter
-                // that rejects almost everything): reported, never answered approximately
+            } else {
+                // more live candidates outside the result set than the largest array holds (a filter that
+                // rejects almost everything; without a filter: more equal-distance keys at the bound than
+                // fit behind it, i.e. hundreds of duplicate vectors): reported, never answered approximately
                 for (uint32_t i = lane; i < k; i += 64) {
                     od[i] = __builtin_nanf("");
                     ol[i] = ~0ull;
@@ -708,7 +711,7 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) {
-        const uint32_t blocks = a.nq < kLargeBlocks ? a.nq : kLargeBlocks;
+        const uint32_t blocks = a.nq < a.large_blocks ? a.nq : a.large_blocks;
         if (a.g.metric == 0)
             hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, RL, 2, true, FILT>), dim3(blocks), dim3(64),
                                (size_t)64 * RL * 12, stream, a);
@@ -768,6 +771,10 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
         if (err) *err = "hnsw_search: workspace missing";
         return 1;
     }
+    if (g.n && (g.entry >= g.n || g.max_level < 0)) {  // the descent would start at a row that does not exist
+        if (err) *err = "hnsw_search: the graph has elements but no entry point";
+        return 2;
+    }
     SearchArgs a;
     a.g = g;
     a.queries = d_queries;
@@ -794,6 +801,7 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
     a.spill_tables = work.spill ? work.spill_tables : 0u;
     a.bitmaps = work.bitmaps;
     a.bitmap_words = work.bitmap_words;
+    a.large_blocks = work.large_blocks ? work.large_blocks : 1u;
     a.ghash = work.ghash;
     a.report = work.report;
     hipError_t e = hipMemsetAsync(work.redo, 0, kRedoHeader * sizeof(uint32_t), stream);

@@ -399,6 +399,24 @@ void HostIndex::link_elements(const uint32_t* ids, size_t n, int n_threads) {
     if (failed) throw std::runtime_error(err);
 }
 
+void HostIndex::truncate_to_empty() {
+    const size_t n = count;
+    for (size_t i = 0; i < n; ++i) {
+        if (upper[i]) std::free(upper[i]);
+        upper[i] = nullptr;
+        levels[i] = 0;
+    }
+    {
+        std::unique_lock<std::mutex> g(label_lock_);
+        label_map_.clear();
+    }
+    count = 0;
+    deleted = 0;
+    entry = 0xFFFFFFFFu;
+    max_level = -1;
+    ++version;
+}
+
 void HostIndex::add_batch(const float* vecs, const uint64_t* labels, size_t n, int n_threads, int forced_level) {
     if (n == 0) return;
     const size_t base = append_unlinked(vecs, labels, n, forced_level);
@@ -504,6 +522,13 @@ HostIndex::HostIndex(const std::string& path, int metric_, size_t dim_, size_t c
     size_t del = 0;
     for (size_t i = 0; i < n; ++i) del += is_deleted((uint32_t)i);
     deleted = del;
+    // searchKnn starts at entry_id_ on max_level_ (:1111-1114) without looking: a file that names an entry
+    // point outside the index, or one without that many levels, is corrupt (link targets are validated per
+    // level when the graph is repacked for the device, capi.cpp upload)
+    if (n != 0 && (entry >= n || max_level < 0 || levels[entry] != max_level)) {
+        release();
+        throw std::runtime_error("Index seems to be corrupted or unsupported");
+    }
     refresh_dist();
 }
 

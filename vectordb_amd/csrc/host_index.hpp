@@ -94,6 +94,10 @@ public:
         ++version;
     }
     void link_elements(const uint32_t* ids, size_t n, int n_threads);
+    // Undo for the device builder: drop every element (rows, labels, levels, lists), keep the capacity.
+    void truncate_to_empty();
+    uint64_t rng_state() const { return rng_.s; }
+    void set_rng_state(uint64_t s) { rng_.s = s; }
     void save(const std::string& path) const;
     void mark_delete(uint64_t label, bool undo);
     void resize(size_t new_capacity);

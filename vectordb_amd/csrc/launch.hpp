@@ -30,8 +30,9 @@ struct HnswSearchWork {
     uint32_t spill_tables = 0;
     uint32_t* spill = nullptr;    // nullable: [spill_tables << kSpillBits] u32, second-level visited tables in HBM for the
                                   // queries that fill their LDS table (any contents: a table is cleared when taken)
-    uint32_t* bitmaps = nullptr;  // [kLargeBlocks][bitmap_words]
+    uint32_t* bitmaps = nullptr;  // [large_blocks][bitmap_words]
     uint32_t bitmap_words = 0;
+    uint32_t large_blocks = kLargeBlocks;  // resident waves of the large configuration (one bitmap each)
 };
 
 // Enqueues the search of nq queries on `stream` (two launches: fast configuration, then the

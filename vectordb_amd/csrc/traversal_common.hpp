@@ -72,7 +72,8 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-// Scores up to 32 nodes.  In: lane r (< m) holds node id ids[r].  Out: lane r (< m) holds
+// Scores up to 64 nodes (the search kernels pass at most 32 at a time, the builder's heuristic up to
+// maxM0 <= 64 kept neighbours).  In: lane r (< m) holds node id ids[r].  Out: lane r (< m) holds
 // the ordered-u32 distance of node r; the other lanes hold garbage.
 // NCH = number of 64-float chunks per row that are touched; GPB = 16-lane groups whose
 // loads are issued before the first FMA (4 nodes each).

@@ -119,6 +119,10 @@ class HierarchicalNSW:
     def setefSearch(self, ef: int) -> None:
         check(self._l.vdb_index_set_ef(self._h, ef))
 
+    def set_spill_mode(self, mode: int) -> None:
+        """-1 adaptive (default), 0 never, 1 always: second-level visited tables in HBM (vdb_index_set_spill_mode)."""
+        check(self._l.vdb_index_set_spill_mode(self._h, mode))
+
     def markDelete(self, label: int) -> None:
         check(self._l.vdb_index_mark_delete(self._h, label))
 

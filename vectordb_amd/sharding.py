@@ -48,11 +48,13 @@ def all_gather_results(dist, label):
     import torch
     import torch.distributed as td
 
+    if not (td.is_available() and td.is_initialized()):   # one shard: the "gathered" lists are the rank's own
+        return dist.unsqueeze(0), label.unsqueeze(0)
     world = td.get_world_size()
     nq = dist.shape[0]
     if dist.is_cuda and td.get_backend() == "gloo":
-        # gloo on GPU tensors (only the one-GPU rehearsal of bench.py does this) stalls after the first
-        # call with two ranks on one device: stage through the host there
+        # gloo is the CPU backend: device tensors go through the host (only the one-GPU rehearsal of
+        # bench.py and the CPU tests get here; on a GPU node the backend is nccl = RCCL)
         gd, gl = all_gather_results(dist.cpu(), label.cpu())
         return gd.to(dist.device), gl.to(label.device)
     gd = torch.empty((world * nq,) + tuple(dist.shape[1:]), dtype=dist.dtype, device=dist.device)
@@ -62,11 +64,22 @@ def all_gather_results(dist, label):
     return gd.view((world,) + tuple(dist.shape)), gl.view((world,) + tuple(label.shape))
 
 
-def sharded_search(shard_index, queries, k: int):
+def sharded_search(shard_index, queries, k: int, events=None):
     """Search this rank's shard, exchange, merge on the GPU.  `queries` is a CUDA tensor holding
-    the SAME batch on every rank.  Returns (dist, label) [nq, k], identical on every rank."""
+    the SAME batch on every rank.  Returns (dist, label) [nq, k], identical on every rank.
+    `events`: four torch.cuda.Event recorded on the current stream around the three stages
+    (search | all-gather | merge), for bench.py's split timing."""
     from . import index as vi
 
+    if events is not None:
+        events[0].record()
     d, l = shard_index.search_batch(queries, k)
+    if events is not None:
+        events[1].record()
     gd, gl = all_gather_results(d, l)
-    return vi.merge_topk(gd, gl)
+    if events is not None:
+        events[2].record()
+    out = vi.merge_topk(gd, gl)
+    if events is not None:
+        events[3].record()
+    return out
