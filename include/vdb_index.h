@@ -145,6 +145,18 @@ size_t vdb_index_device_bytes(const vdb_index* idx);
  * (:1141-1148: they are traversed, never returned). */
 int vdb_search_batch_device(const vdb_index* idx, const float* d_queries, size_t nq, size_t k,
                             float* d_out_dist, uint64_t* d_out_label, uint32_t* d_out_stats, void* stream);
+/* vdb_search_batch_device for callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference (it has no
+ * device).  Same arguments, same results bit for bit, and it calls no hipMalloc / hipFree / allocating
+ * library routine: the traversal's scratch (the work list of queries that outgrow their LDS visited table
+ * and the visited bitmaps of the waves that re-run them) lives in a static device array of the library,
+ * about 4.1 MB per GPU, held until the process ends.  Limits (VDB_ERR_INVALID beyond them): nq <= 32768
+ * queries per call, index of at most 2^23 elements.  No caller's filter; deleted elements are skipped as
+ * above.  A query whose key array overflows (hundreds of equal distances) is reported as described at
+ * vdb_search_batch_device_filtered.  Every call on a GPU shares that GPU's array: calls that overlap
+ * on one GPU (two streams, two threads) race - serialise them. */
+int vdb_search_batch_device_noalloc(const vdb_index* idx, const float* d_queries, size_t nq, size_t k,
+                                    float* d_out_dist, uint64_t* d_out_label, uint32_t* d_out_stats, void* stream);
 /* Same with HOST pointers (copies in and out, synchronises; PCIe-inclusive). */
 int vdb_search_batch(const vdb_index* idx, const float* queries, size_t nq, size_t k, float* out_dist,
                      uint64_t* out_label, uint32_t* out_stats);

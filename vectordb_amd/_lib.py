@@ -53,6 +53,7 @@ SIGNATURES = {
     "vdb_index_to_device": (C.c_int, [_vp, C.c_int]),
     "vdb_index_device_bytes": (C.c_size_t, [_vp]),
     "vdb_search_batch_device": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp, _vp, _vp]),
+    "vdb_search_batch_device_noalloc": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp, _vp, _vp]),
     "vdb_search_batch": (C.c_int, [_vp, _f32p, C.c_size_t, C.c_size_t, _f32p, _u64p, _u32p]),
     "vdb_search_batch_device_filtered": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp, _vp, _vp, _vp]),
     "vdb_search_batch_filtered": (C.c_int, [_vp, _f32p, C.c_size_t, C.c_size_t, _u32p, _f32p, _u64p, _u32p]),

@@ -407,6 +407,11 @@ void upload(vdb_index* idx, int device) {
     g.entry = h.entry;
     g.max_level = h.max_level;
     g.metric = h.metric;
+    {  // set-up of the no-allocation entry point: this device's address of the static scratch array
+        void* p = nullptr;
+        std::string err;
+        if (noalloc_scratch(device, &p, &err) != 0) throw DeviceError(err);
+    }
     idx->device = device;
     idx->device_version = h.version;
 }
@@ -1044,6 +1049,47 @@ int vdb_search_batch_device_filtered(const vdb_index* cidx, const float* d_queri
     return guarded([&] {
         return search_device(const_cast<vdb_index*>(cidx), d_queries, nq, k, d_allow, d_out_dist, d_out_label, d_out_stats,
                              (hipStream_t)stream_, nullptr);
+    });
+}
+
+// vdb_search_batch_device for callers that cannot allocate: no hipMalloc / hipFree / hipHostMalloc here or
+// below (launch_hnsw_search enqueues one hipMemsetAsync and the kernels); the work list and the visited
+// bitmaps of the large configuration live in the library's static device array (noalloc_scratch.hip).
+int vdb_search_batch_device_noalloc(const vdb_index* cidx, const float* d_queries, size_t nq, size_t k, float* d_out_dist,
+                                    uint64_t* d_out_label, uint32_t* d_out_stats, void* stream_) {
+    return guarded([&] {
+        vdb_index* idx = const_cast<vdb_index*>(cidx);
+        require_search_ready(idx);
+        if (nq == 0) return (int)VDB_OK;
+        if (!d_queries || !d_out_dist || !d_out_label) throw std::invalid_argument("null buffer");
+        if (k == 0) throw std::invalid_argument("k must be > 0");
+        if (nq > kNoAllocMaxQueries)
+            throw std::invalid_argument("vdb_search_batch_device_noalloc: at most " + std::to_string(kNoAllocMaxQueries) +
+                                        " queries per call (split the batch, or use vdb_search_batch_device)");
+        if (idx->graph.n > kNoAllocMaxElements)
+            throw std::invalid_argument("vdb_search_batch_device_noalloc: at most " + std::to_string(kNoAllocMaxElements) +
+                                        " elements per index (use vdb_search_batch_device)");
+        const size_t ef = std::max(idx->host->ef_search, k);  // hnsw_core.hpp:1144
+        if (ef > kMaxEf) throw Unsupported("max(efSearch, k) above 508 is not supported by the device path");
+        DeviceGuard guard(idx->device);
+        void* base = nullptr;
+        std::string err;
+        int rc = noalloc_scratch(idx->device, &base, &err);
+        if (rc != 0) return set_error(rc, err);
+        HnswSearchWork work;
+        work.redo = (uint32_t*)base;
+        work.bitmaps = (uint32_t*)((char*)base + kNoAllocBitmapOffset);
+        work.bitmap_words = std::max((idx->graph.n + 31u) / 32u, 1u);
+        work.large_blocks = kNoAllocLargeBlocks;
+        {
+            std::unique_lock<std::mutex> lock(idx->scratch_lock);
+            auto it = idx->hbits_bias.find((uint32_t)ef);
+            work.hbits_bias = it == idx->hbits_bias.end() ? 0u : it->second;
+        }
+        rc = launch_hnsw_search(idx->graph, d_queries, (uint32_t)nq, (uint32_t)k, (uint32_t)ef, (const uint32_t*)idx->live.p,
+                                d_out_dist, d_out_label, d_out_stats, work, (hipStream_t)stream_, &err);
+        if (rc != 0) return set_error(rc, err);
+        return (int)VDB_OK;
     });
 }
 

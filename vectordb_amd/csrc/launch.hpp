@@ -21,6 +21,17 @@ constexpr uint32_t kSpillTablesMin = 512;  // spill tables per launch: nq / 16 w
 constexpr uint32_t kSpillTablesMax = 4096; // finds none left is re-run by the large configuration
 constexpr uint32_t kRedoHeader = 4;        // words ahead of the re-run list
 
+// The no-allocation entry point (vdb_search_batch_device_noalloc): limits and the layout of its static
+// scratch (noalloc_scratch.hip): [work list: kRedoHeader + kNoAllocMaxQueries words | pad to 256 B |
+// kNoAllocLargeBlocks visited bitmaps of kNoAllocMaxElements bits].
+constexpr uint32_t kNoAllocMaxQueries = 32768;
+constexpr uint32_t kNoAllocMaxElements = 1u << 23;
+constexpr uint32_t kNoAllocLargeBlocks = 4;
+constexpr size_t kNoAllocBitmapOffset = (((size_t)kRedoHeader + kNoAllocMaxQueries) * 4 + 255) / 256 * 256;
+constexpr size_t kNoAllocScratchBytes = kNoAllocBitmapOffset + (size_t)kNoAllocLargeBlocks * (kNoAllocMaxElements / 32) * 4;
+// Address of that scratch on `device` (which must be current); asked from the runtime once per device.
+int noalloc_scratch(int device, void** out, std::string* err);
+
 struct HnswSearchWork {
     uint32_t* ghash = nullptr;    // nullable: [kGlobalHashBlocks << kGlobalHashBits] u32, visited tables in HBM (large ef)
     uint32_t* report = nullptr;   // nullable, host-mapped [2]: {queries re-run by the large configuration, nq} of this launch

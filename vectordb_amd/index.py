@@ -232,6 +232,18 @@ class HierarchicalNSW:
                                                 st.ctypes.data_as(_u32p) if stats else None))
         return (dist, label, st) if stats else (dist, label)
 
+    def search_batch_noalloc(self, queries, dist, label, stats=None) -> None:
+        """vdb_search_batch_device_noalloc: CUDA tensors in, results into the caller's CUDA tensors
+        (dist [nq,k] f32, label [nq,k] int64, stats nullable [nq,4] int32); nothing is allocated."""
+        nq, k = dist.shape
+        if queries.shape != (nq, self.space.dim) or label.shape != (nq, k) or not (queries.is_contiguous() and dist.is_contiguous() and label.is_contiguous()):
+            raise ValueError("search_batch_noalloc: contiguous [nq, dim] queries, [nq, k] dist and label")
+        import torch
+
+        stream = torch.cuda.current_stream(queries.device).cuda_stream
+        check(self._l.vdb_search_batch_device_noalloc(self._h, queries.data_ptr(), nq, k, dist.data_ptr(), label.data_ptr(),
+                                                      stats.data_ptr() if stats is not None else None, stream))
+
     def SearchKNNCloserFirst(self, query, k: int, filter=None):  # hnswlib.hpp:87-99
         d, l = self.search_batch(np.asarray(query, np.float32).reshape(1, -1), k, filter=filter)
         keep = l[0] != np.uint64(0xFFFFFFFFFFFFFFFF)
