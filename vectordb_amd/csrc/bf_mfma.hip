@@ -38,6 +38,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <type_traits>
 
@@ -160,6 +161,8 @@ struct QPrepArgs {
     __bf16* qb;          // bf16 panels, round_up(nq, 256) rows
     float* off;          // [nq]  dist ~= score + off
     float* eps;          // [nq]  |approx dist - exact tree64 dist| <= eps  (f32 pass)
+    float scale;         // the panel copies hold scale * qc: -2 (L2) / -1 (IP), so that the GEMM's accumulators,
+                         // started at ||xc||^2 (L2) / 0 (IP), ARE the scores (a power of two: exact in f32 and bf16)
 };
 
 __global__ __launch_bounds__(256) void bf_prep_queries(QPrepArgs a) {
@@ -178,8 +181,8 @@ __global__ __launch_bounds__(256) void bf_prep_queries(QPrepArgs a) {
             v = is_l2 ? raw - a.mu[c] : raw;
             qmu += (double)raw * (double)a.mu[c];
         }
-        if (c < a.vstride) a.qf[panel_f32(q, c, ksf)] = v;
-        a.qb[panel_bf16(q, c, ksb)] = (__bf16)v;
+        if (c < a.vstride) a.qf[panel_f32(q, c, ksf)] = a.scale * v;
+        a.qb[panel_bf16(q, c, ksb)] = (__bf16)(a.scale * v);
         sq += (double)v * (double)v;
     }
     if (!real) return;
@@ -213,6 +216,12 @@ struct GemmArgs {
     uint32_t* count;
     const uint32_t* tauhat;  // [round_up(nq, 256)] ordered-u32 threshold on the approximate distance
     uint64_t* entries;       // [nq][cap]  ord(approx dist) << 32 | row
+    // the block's count of listed pairs: the pairs that pass go to a list of the BLOCK (slot from a counter in LDS, plain stores:
+    // nothing to wait for), and bf_scatter_hits appends them to the queries' buffers afterwards
+    uint64_t* hit_key;       // [kGemmBlocks][hit_cap]
+    uint32_t* hit_q;         // [kGemmBlocks][hit_cap]
+    uint32_t* hit_count;     // [kGemmBlocks]
+    uint32_t hit_cap;
 };
 
 // LDS image of one operand tile of one k-step: 256 rows x 64 B, no padding (LDS-DMA writes 1 KiB
@@ -227,6 +236,7 @@ constexpr int kStages = 4;                    // ring of k-steps in LDS: 3 in fl
 constexpr int kAuxBytes = 3 * 1024;           // per tile: 256 x (||xc||^2, tau_hat, query offset)
 constexpr int kGemmThreads = 512;             // 8 waves: 2 (rows) x 4 (queries), 128 x 64 outputs each
 constexpr int kGemmBlocks = 256;              // persistent: one block per CU (LDS admits no second)
+constexpr uint32_t kHitCap = 16384;           // listed pairs per block and launch (12 B each); beyond: appended directly
 constexpr int kPiecesPerWave = 4;             // 32 pieces (16 A + 16 B) per k-step over 8 waves
 
 // Persistent tile loop.  Block b sits on XCD b % 8 (round-robin dispatch; placement is speed, not
@@ -239,12 +249,24 @@ constexpr int kPiecesPerWave = 4;             // 32 pieces (16 A + 16 B) per k-s
 // (filter + append) runs with those loads in flight.  With one block per tile the pipeline fill,
 // the block launch and a scalar epilogue cost more than the K loop itself (17 us against 15 us per
 // tile at d = 960, measured by emptying the loop).
-template <bool BF16>
+__device__ __forceinline__ unsigned long long stamp() {  // diagnostic build only (STAMPS)
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+// STAMPS: diagnostic build (tools/exp_gemm.py, VDB_GEMM_STAMPS=1): s_memtime stamps around the parts of the
+// loop, printed by two blocks of one launch; never what a search call runs.
+template <bool BF16, bool STAMPS>
 __global__ __launch_bounds__(kGemmThreads) void bf_gemm_filter(GemmArgs a) {
     // one LDS object: the ring + four tiles' worth of epilogue inputs (a second __shared__ array
     // beside an LDS-DMA target makes hipcc drain the DMA before every LDS read)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[kStages * kStageBytes + 4 * kAuxBytes];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kStages * kStageBytes + 4 * kAuxBytes + 16];
     unsigned char* aux_s = smem + kStages * kStageBytes;
+    uint32_t* hit_ctr = reinterpret_cast<uint32_t*>(smem + kStages * kStageBytes + 4 * kAuxBytes);  // the block's count of listed pairs
+    const uint32_t hit_ctr_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)hit_ctr;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar
     const int wr = wave >> 2, wc = wave & 3, h = lane >> 5, li = lane & 31;
     const uint32_t xcd = blockIdx.x & 7u, in = blockIdx.x >> 3;
@@ -266,7 +288,11 @@ __global__ __launch_bounds__(kGemmThreads) void bf_gemm_filter(GemmArgs a) {
     // each).  Every wave issues 4 (+1) instructions per k-step, in stream order: that is what the
     // counted waits below rely on; extra instructions only make them conservative.
     uint32_t tr_i = 0, tq_i = 0, s_iss = next_tile(xcd, tr_i, tq_i);
-    if (s_iss >= n_sup) return;  // no tile for this block (uniform over the block)
+    if (s_iss >= n_sup) {  // no tile for this block (uniform over the block)
+        if (tid == 0) a.hit_count[blockIdx.x] = 0u;
+        return;
+    }
+    if (tid == 0) *hit_ctr = 0u;  // (ahead of the prologue's barrier)
     uint32_t ks_iss = 0, tile_iss = 0;
     bool iss_live = true;
     const char* src[kPiecesPerWave];
@@ -382,76 +408,106 @@ __global__ __launch_bounds__(kGemmThreads) void bf_gemm_filter(GemmArgs a) {
     // loop hipcc waits for ALL LDS reads, the fresh a1/b1 ones included, ahead of the first MFMA)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(b0[0]), "+v"(b0[1]));
     uint32_t g = 0, tile_cmp = 0, tr = 0, tq = 0;
+    unsigned long long d_wait = 0, d_h1 = 0, d_mid = 0, d_h2 = 0, d_epi = 0, d_init = 0, t_begin = 0, rt_begin = 0;
+    if constexpr (STAMPS) {
+        t_begin = stamp();
+        rt_begin = __builtin_amdgcn_s_memrealtime();
+    }
     for (uint32_t s_cmp = next_tile(xcd, tr, tq); s_cmp < n_sup; s_cmp = next_tile(s_cmp + 8u, tr, tq), ++tile_cmp) {
+        unsigned long long ts0 = 0;
+        if constexpr (STAMPS) ts0 = stamp();
+        if (is_l2) {
+            // this tile's ||xc||^2 arrived with its first k-step (landed: the wait + barrier that released that step)
+            const float* nx0 = reinterpret_cast<const float*>(aux_s + (tile_cmp & 3u) * kAuxBytes) + wr * 128 + 4 * h;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 nv = *reinterpret_cast<const f32x4*>(nx0 + m * 32 + 8 * j);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[m][n][4 * j + i] = nv[i];
+                }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        }
 
+        if constexpr (STAMPS) d_init += stamp() - ts0;
         for (uint32_t ks = 0; ks < nk; ++ks, ++g) {
+            unsigned long long t0 = 0, t1 = 0, t2 = 0;
+            if constexpr (STAMPS) t0 = stamp();
             const int slot = (int)(g & (kStages - 1)), nslot = (int)((g + 1) & (kStages - 1));
             const int fill = (int)((g + kStages - 1) & (kStages - 1));  // step g+3 goes where g-1 was
             stage_begin();
-            // first half: MFMAs of k-block 0 (a0, b0); reads of k-block 1; the early issuers' DMA
-            if (early) stage_piece(fill, 0);
+            // DMA placement: the k-step has eight places, one ahead of each MFMA group; the waves of row half 0
+            // issue their four pieces at places 0, 2, 4, 6, their SIMD partners (waves 4-7) at 1, 3, 5, 7, so that
+            // the pieces reach the vector-memory path evenly spread (four in one half, the partners in the other
+            // half, measured 3 % slower).
+            auto dma_at = [&](int place) {
+                if (early == ((place & 1) == 0)) stage_piece(fill, place >> 1);
+            };
+            // first half: MFMAs of k-block 0 (a0, b0); reads of k-block 1
+            dma_at(0);
             a1[0] = read_a(slot, 1, 0);
             a1[1] = read_a(slot, 1, 1);
             __builtin_amdgcn_sched_barrier(0);
             mma_m(I0{}, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            if (early) stage_piece(fill, 1);
+            dma_at(1);
             a1[2] = read_a(slot, 1, 2);
             a1[3] = read_a(slot, 1, 3);
             __builtin_amdgcn_sched_barrier(0);
             mma_m(I1{}, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            if (early) stage_piece(fill, 2);
+            dma_at(2);
             b1[0] = read_b(slot, 1, 0);
             b1[1] = read_b(slot, 1, 1);
             __builtin_amdgcn_sched_barrier(0);
             mma_m(I2{}, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            if (early) stage_piece(fill, 3);
+            dma_at(3);
             __builtin_amdgcn_sched_barrier(0);
             mma_m(I3{}, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            // step g+1 landed: behind it the early issuers have 8 younger instructions, the late 4.
+            // step g+1 landed: behind its pieces a wave has the 4 of step g+2 and the 2 of step g+3 it issued in
+            // this half - extra instructions (aux, the epilogue's stores) only make the wait conservative.
             // (a1/b1 named as operands: hipcc then knows they are complete and puts no wait of its
             // own, which would cover the fresh a0/b0 reads as well, ahead of the MFMAs below)
-            if (early)
-                asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)"
-                             : "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]), "+v"(b1[0]), "+v"(b1[1])
-                             :
-                             : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)"
-                             : "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]), "+v"(b1[0]), "+v"(b1[1])
-                             :
-                             : "memory");
+            if constexpr (STAMPS) t1 = stamp();
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)"
+                         : "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]), "+v"(b1[0]), "+v"(b1[1])
+                         :
+                         : "memory");
+            if constexpr (STAMPS) d_wait += stamp() - t1;
             __builtin_amdgcn_s_barrier();
+            if constexpr (STAMPS) t2 = stamp();
             // second half: MFMAs of k-block 1 (a1, b1); reads of the next step's k-block 0 (slot + 1
-            // holds landed data: the next k-step, the next tile's first, or the re-read); late DMA
-            if (!early) stage_piece(fill, 0);
+            // holds landed data: the next k-step, the next tile's first, or the re-read)
+            dma_at(4);
             a0[0] = read_a(nslot, 0, 0);
             a0[1] = read_a(nslot, 0, 1);
             __builtin_amdgcn_sched_barrier(0);
             mma_m(I0{}, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
-            if (!early) stage_piece(fill, 1);
+            dma_at(5);
             a0[2] = read_a(nslot, 0, 2);
             a0[3] = read_a(nslot, 0, 3);
             __builtin_amdgcn_sched_barrier(0);
             mma_m(I1{}, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
-            if (!early) stage_piece(fill, 2);
+            dma_at(6);
             b0[0] = read_b(nslot, 0, 0);
             b0[1] = read_b(nslot, 0, 1);
             __builtin_amdgcn_sched_barrier(0);
             mma_m(I2{}, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
-            if (!early) stage_piece(fill, 3);
+            dma_at(7);
             __builtin_amdgcn_sched_barrier(0);
             mma_m(I3{}, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
@@ -460,7 +516,15 @@ __global__ __launch_bounds__(kGemmThreads) void bf_gemm_filter(GemmArgs a) {
             // iteration's first MFMA does not wait for the a1/b1 reads issued just before it
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(b0[0]), "+v"(b0[1]));
+            if constexpr (STAMPS) {
+                const unsigned long long t3 = stamp();
+                d_h1 += t1 - t0;
+                d_mid += t2 - t1;
+                d_h2 += t3 - t2;
+            }
         }
+        unsigned long long te0 = 0;
+        if constexpr (STAMPS) te0 = stamp();
 
         // Epilogue: column = query (lane & 31), registers = base rows.  approx dist = (nx - 2 dot) +
         // off; pairs at or below the query's running threshold are appended to its candidate buffer.
@@ -468,7 +532,6 @@ __global__ __launch_bounds__(kGemmThreads) void bf_gemm_filter(GemmArgs a) {
         // screened by their minimum against a threshold moved to the dot's side of the sum (with
         // slack for the rounding of that move); only a screened group runs the exact test.
         const unsigned char* aux = aux_s + (tile_cmp & 3u) * kAuxBytes;
-        const float* nx_s = reinterpret_cast<const float*>(aux);
         const uint32_t* th_s = reinterpret_cast<const uint32_t*>(aux + 1024);
         const float* off_s = reinterpret_cast<const float*>(aux + 2048);
         const uint32_t row0 = a.row_lo + tr * kTile, q0 = tq * kTile;
@@ -484,16 +547,10 @@ __global__ __launch_bounds__(kGemmThreads) void bf_gemm_filter(GemmArgs a) {
             screen = !qok ? -__builtin_inff() : open ? __builtin_inff() : screen;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
+                // the accumulators are the scores already: ||xc||^2 - 2 dot (L2), -dot (IP)
                 float sc[16];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 nv = *reinterpret_cast<const f32x4*>(nx_s + wr * 128 + m * 32 + 8 * j + 4 * h);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float dot = acc[m][n][4 * j + i];
-                        sc[4 * j + i] = is_l2 ? nv[i] - 2.0f * dot : -dot;
-                    }
-                }
+                for (int r = 0; r < 16; ++r) sc[r] = acc[m][n][r];
                 float mn = sc[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) mn = __builtin_fminf(mn, sc[r]);
@@ -503,14 +560,55 @@ __global__ __launch_bounds__(kGemmThreads) void bf_gemm_filter(GemmArgs a) {
                     const uint32_t row = row0 + wr * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     const float dh = sc[r] + offq;
                     if (qok && row < a.row_hi && (open || dh <= tauf)) {
-                        const uint32_t pos = atomicAdd(&a.count[q], 1u);
-                        if (pos < a.cap) a.entries[(size_t)q * a.cap + pos] = ((uint64_t)f2ord(dh) << 32) | row;
+                        const uint64_t key = ((uint64_t)f2ord(dh) << 32) | row;
+                        // The pair goes to the BLOCK's list: a slot from a counter in LDS and two plain stores, nothing
+                        // to wait for; bf_scatter_hits appends the lists to the queries' buffers after the GEMM.  (A
+                        // returning global atomic here is waited for with vmcnt, i.e. behind every DMA piece in flight.
+                        // Inline asm: with LDS-DMA in flight hipcc puts vmcnt(0) in front of an LDS atomic it knows of.)
+                        bool listed = false;
+                        uint32_t slot;
+                        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(slot) : "v"(hit_ctr_addr), "v"(1u) : "memory");
+                        if (slot < a.hit_cap) {
+                            a.hit_key[(size_t)blockIdx.x * a.hit_cap + slot] = key;
+                            a.hit_q[(size_t)blockIdx.x * a.hit_cap + slot] = q;
+                            listed = true;
+                        }
+                        if (!listed) {
+                            const uint32_t pos = atomicAdd(&a.count[q], 1u);
+                            if (pos < a.cap) a.entries[(size_t)q * a.cap + pos] = key;
+                        }
                     }
                 }
             }
         }
+        if constexpr (STAMPS) d_epi += stamp() - te0;
+    }
+    if constexpr (STAMPS) {
+        const unsigned long long t_end = stamp(), rt_end = __builtin_amdgcn_s_memrealtime();
+        if (a.row_lo == 229376u && (blockIdx.x == 0 || blockIdx.x == 77) && lane == 0)
+            printf("[gemm stamps] block %u wave %d: tiles %u ksteps %u | total %llu cyc, %llu ticks of 10 ns (%.3f GHz) | half1 %llu mid-wait+barrier %llu (wait alone %llu) half2 %llu "
+                   "init %llu epilogue %llu\n",
+                   blockIdx.x, wave, tile_cmp, g, t_end - t_begin, rt_end - rt_begin,
+                   (double)(t_end - t_begin) / (double)(rt_end - rt_begin) / 10.0, d_h1, d_mid, d_wait, d_h2, d_init, d_epi);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tid == 0) {
+        const uint32_t c = *hit_ctr;
+        a.hit_count[blockIdx.x] = c < a.hit_cap ? c : a.hit_cap;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the over-issued steps before LDS is released
+}
+
+// the listed pairs of every block -> the queries' candidate buffers (the returning atomics live here)
+__global__ __launch_bounds__(256) void bf_scatter_hits(const uint64_t* hit_key, const uint32_t* hit_q, const uint32_t* hit_count,
+                                                       uint32_t hit_cap, uint32_t* count, uint64_t* entries, uint32_t cap) {
+    const uint32_t b = blockIdx.x >> 2, n = hit_count[b];
+    for (uint32_t i = (blockIdx.x & 3u) * 256u + threadIdx.x; i < n; i += 1024u) {
+        const uint32_t q = hit_q[(size_t)b * hit_cap + i];
+        const uint32_t pos = atomicAdd(&count[q], 1u);
+        if (pos < cap) entries[(size_t)q * cap + pos] = hit_key[(size_t)b * hit_cap + i];
+    }
 }
 
 // ------------------------------------------------------------------ exact re-rank
@@ -578,6 +676,16 @@ __global__ __launch_bounds__(64) void bf_rerank(RerankArgs a) {
     }
 }
 
+void launch_gemm(bool bf16, dim3 grid, hipStream_t stream, const GemmArgs& g) {
+    static const bool stamps = std::getenv("VDB_GEMM_STAMPS") != nullptr;  // diagnostics (bf16 only), tools/exp_gemm.py
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), 0, stream, g); };
+    if (!bf16) go(bf_gemm_filter<false, false>);
+    else if (stamps) go(bf_gemm_filter<true, true>);
+    else go(bf_gemm_filter<true, false>);
+    hipLaunchKernelGGL(bf_scatter_hits, dim3(kGemmBlocks * 4), dim3(256), 0, stream, g.hit_key, g.hit_q, g.hit_count, g.hit_cap,
+                       g.count, g.entries, g.cap);
+}
+
 template <typename T>
 T* carve(char*& p, size_t count) {
     T* r = reinterpret_cast<T*>(p);
@@ -627,6 +735,9 @@ size_t bf_mfma_workspace_bytes(uint32_t nq, uint32_t vstride, uint32_t kp64) {
     add(((size_t)nq + 255) / 256 * 256 * 4);  // off (same)
     add((size_t)nq * 4 * 2);              // eps, cert
     add(((size_t)nq + 1) * 4);            // redo
+    add((size_t)kGemmBlocks * kHitCap * 8);  // hit_key
+    add((size_t)kGemmBlocks * kHitCap * 4);  // hit_q
+    add((size_t)kGemmBlocks * 4);            // hit_count
     return b + 4096 + bf_exact_workspace_bytes(nq);
 }
 
@@ -650,6 +761,9 @@ int launch_bf_mfma(const BfDeviceData& d, int precision, const float* d_queries,
     float* eps = carve<float>(p, nq);
     float* cert = carve<float>(p, nq);
     uint32_t* redo = carve<uint32_t>(p, (size_t)nq + 1);
+    uint64_t* hit_key = carve<uint64_t>(p, (size_t)kGemmBlocks * kHitCap);
+    uint32_t* hit_q = carve<uint32_t>(p, (size_t)kGemmBlocks * kHitCap);
+    uint32_t* hit_count = carve<uint32_t>(p, kGemmBlocks);
     void* exact_ws = p;
 
     hipError_t e = hipMemsetAsync(count, 0, (size_t)nq * 4, stream);
@@ -661,7 +775,8 @@ int launch_bf_mfma(const BfDeviceData& d, int precision, const float* d_queries,
         return 3;
     }
 
-    QPrepArgs qa{d_queries, nq, d.dim, d.vstride, d.kp64, d.metric, d.mu, d.stats, qf, qb, off, eps};
+    QPrepArgs qa{d_queries, nq, d.dim, d.vstride, d.kp64, d.metric, d.mu, d.stats, qf, qb, off, eps,
+                 d.metric == 0 ? -2.0f : -1.0f};
     hipLaunchKernelGGL(bf_prep_queries, dim3((uint32_t)((nqpad + 3) / 4)), dim3(256), 0, stream, qa);
 
     GemmArgs g{};
@@ -676,6 +791,10 @@ int launch_bf_mfma(const BfDeviceData& d, int precision, const float* d_queries,
     g.count = count;
     g.tauhat = tauhat;
     g.entries = entries;
+    g.hit_key = hit_key;
+    g.hit_q = hit_q;
+    g.hit_count = hit_count;
+    g.hit_cap = kHitCap;
 
     CompactArgs c{};
     c.nq = nq;
@@ -700,8 +819,7 @@ int launch_bf_mfma(const BfDeviceData& d, int precision, const float* d_queries,
         g.tiles_r = (hi - lo + kTile - 1) / kTile;
         g.tiles_q = (nq + kTile - 1) / kTile;
         const dim3 grid(kGemmBlocks);  // persistent: the blocks walk the tiles (see the kernel)
-        if (bf16) hipLaunchKernelGGL((bf_gemm_filter<true>), grid, dim3(kGemmThreads), 0, stream, g);
-        else hipLaunchKernelGGL((bf_gemm_filter<false>), grid, dim3(kGemmThreads), 0, stream, g);
+        launch_gemm(bf16, grid, stream, g);
         e = hipGetLastError();
         if (e == hipSuccess) e = enqueue_bf_compact(c, stream);
         if (e != hipSuccess) break;
