@@ -717,7 +717,10 @@ int launch_bf_prepare(const float* d_raw, uint32_t n, uint32_t dim, uint32_t vst
 }
 
 uint32_t bf_mfma_kprime(uint32_t k, int precision) {
-    uint32_t kp = precision == 0 ? k + 32 : (4 * k > k + 96 ? 4 * k : k + 96);
+    // candidates kept per query between slabs.  f32: k + 32 (the certificate decides whether that was enough).
+    // bf16: max(2k, k + 32) - every passing pair costs epilogue time (k' = 106 / 64 / 42 / 26 at k = 10: 20.8 / 19.5 /
+    // 18.7 / 18.2 ms per C3 batch, recall@10 1.0000 in all four), and recall is what bf16 reports, not guarantees
+    uint32_t kp = precision == 0 ? k + 32 : (2 * k > k + 32 ? 2 * k : k + 32);
     if (kp > kBfMfmaCap / 2) kp = kBfMfmaCap / 2;
     return kp < k ? k : kp;
 }
