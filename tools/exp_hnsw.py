@@ -11,8 +11,15 @@ n = int(os.environ.get("EXP_N", 1_000_000)); dim = 128
 law = datasets.ClusteredLaw(dim, latent=32)
 base = law.sample(n, seed=1)
 h = vi.HierarchicalNSW(vi.L2Space(dim), n, 16, 200, 100)
-t0 = time.time(); h.add_items(base, n_threads=16); print("build", round(time.time() - t0, 1), flush=True)
+t0 = time.time()
+if os.environ.get("EXP_BUILD", "host") == "device":
+    h.add_items_device(base, n_threads=16)
+else:
+    h.add_items(base, n_threads=16)
+print("build", round(time.time() - t0, 1), flush=True)
 h.to_device(0)
+if os.environ.get("EXP_SPILL"):
+    h.set_spill_mode(int(os.environ["EXP_SPILL"]))
 for nq in [int(x) for x in os.environ.get("EXP_NQ", "10000,20000,40000,100000").split(",")]:
     q = torch.from_numpy(law.sample(nq, seed=2)).cuda()
     for ef in [int(x) for x in os.environ.get("EXP_EF", "32,64").split(",")]:
@@ -22,7 +29,7 @@ for nq in [int(x) for x in os.environ.get("EXP_NQ", "10000,20000,40000,100000").
         st = st.cpu().numpy().view(np.uint32).astype(np.int64)
         alg = (st[:, 0] * 512 + st[:, 1] * 132 + st[:, 2] * 68).sum() + nq * (512 + 120)
         for _ in range(3): h.search_batch(q, 10)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(int(os.environ.get("EXP_REPS", 10)))]
         for a, b in ev:
             a.record(); h.search_batch(q, 10); b.record()
         torch.cuda.synchronize()
