@@ -53,31 +53,30 @@ using namespace dev;
 template <bool SPILL>
 struct LdsVisited {
     uint32_t* tab;
-    uint32_t hbits;
+    uint32_t size;  // entries, a multiple of 256 (not a power of two: the launcher gives a query the share of the
+                    // CU's LDS that its residency leaves, see launch_cfg)
     // Second level, in HBM, taken when the LDS table reaches its fill limit (take_spill): the LDS
     // table is then frozen (looked up, never inserted into) and new ids go to the spill table, so the
     // set stays exact and the search carries on instead of starting again in the large configuration.
     uint32_t* spill;
     __device__ __forceinline__ void clear(int lane) {
-        const uint32_t n = 1u << hbits;
-        for (uint32_t i = lane * 4; i < n; i += 256) *reinterpret_cast<uint4*>(tab + i) = uint4{~0u, ~0u, ~0u, ~0u};
+        for (uint32_t i = lane * 4; i < size; i += 256) *reinterpret_cast<uint4*>(tab + i) = uint4{~0u, ~0u, ~0u, ~0u};
         spill = nullptr;
     }
     // true when `id` was not in the set (and inserts it)
     __device__ __forceinline__ bool test_and_set(uint32_t id) {
-        const uint32_t mask = (1u << hbits) - 1u;
-        uint32_t s = (id * 0x9E3779B1u) >> (32u - hbits);
+        uint32_t s = __umulhi(id * 0x9E3779B1u, size);  // multiplicative hash onto [0, size)
         if (!SPILL || spill == nullptr) {  // (wave-uniform)
             uint32_t old = atomicCAS(&tab[s], kEmptyWord, id);  // almost always decides
             while (old != kEmptyWord && old != id) {
-                s = (s + 1u) & mask;
+                s = s + 1u == size ? 0u : s + 1u;
                 old = atomicCAS(&tab[s], kEmptyWord, id);
             }
             return old == kEmptyWord;
         }
         uint32_t v = tab[s];  // frozen at 75 % fill or less: the probe ends
         while (v != kEmptyWord && v != id) {
-            s = (s + 1u) & mask;
+            s = s + 1u == size ? 0u : s + 1u;
             v = tab[s];
         }
         if (v == id) return false;
@@ -90,7 +89,7 @@ struct LdsVisited {
         }
         return old == kEmptyWord;
     }
-    __device__ __forceinline__ uint32_t limit() const { return (3u << hbits) >> 2; }  // 75 % fill
+    __device__ __forceinline__ uint32_t limit() const { return size - (size >> 2); }  // 75 % fill
     // Called by the whole wave when the next hop could pass the limit; `taken` = the launch's counter of
     // spill tables.  Returns the new limit, or 0 when there is no table to take (none configured,
     // all taken, or this query has one already).
@@ -317,6 +316,7 @@ struct SearchArgs {
     DevGraph g;
     const float* queries;  // [nq][dim]
     uint32_t nq, k, ef, hbits;
+    uint32_t lds_entries;  // LdsVisited::size of this launch
     float* out_dist;       // [nq][k]
     uint64_t* out_label;   // [nq][k]
     uint32_t* out_stats;   // nullable [nq][4]
@@ -340,8 +340,9 @@ struct SearchArgs {
 // blocks walking the batch), 2 exact bitmap in HBM = the large configuration over the re-run list
 // (exact unless the key array itself overflows, which is reported per query: found = UINT32_MAX),
 // 3 = 0 with a second-level table in HBM for the queries that fill the LDS one (LdsVisited).
+// Registers: R <= 2 (ef <= 124, bare) fits 128 VGPRs = four waves per SIMD; left alone the R == 2 body took 129.
 template <int NCH, int GPB, int R, int VIS, bool IS_L2, bool FILT>
-__global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
+__global__ __launch_bounds__(64, (R <= 2 && !FILT && VIS != 2) ? 4 : 2) void hnsw_search_kernel(SearchArgs a) {
     constexpr int S = FILT ? 2 : 1;
     constexpr bool LARGE = VIS == 2;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(64, 2) void hnsw_search_kernel(SearchArgs a) {
         vis.hbits = kGlobalHashBits;
     } else {
         vis.tab = lds;
-        vis.hbits = a.hbits;
+        vis.size = a.lds_entries;
     }
 
     const uint32_t n_work = LARGE ? a.redo[0] : a.nq;
@@ -696,18 +697,33 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
             lds_small = 0;
         }
     }
+    SearchArgs b = a;
     if (lds_small) {
+        // The table gets the share of the CU's LDS that the kernel's register-limited residency leaves to a
+        // query: LDS, not registers, should never be what bounds the chains in flight, and a larger table
+        // than the power of two `hbits` asks for costs nothing then.  When hbits asks for more than that
+        // share (large ef, or raised by the caller after overflows) residency is given up for it.
+        static const uint32_t per_cu = [&] {  // blocks of this instantiation a CU holds by registers alone
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hnsw_search_kernel<NCH, GPB, R, 0, true, FILT>, 64, 1024) != hipSuccess || n <= 0)
+                return 8u;
+            return (uint32_t)n;
+        }();
+        size_t share = ((size_t)160 * 1024 / per_cu) / 1024 * 1024;
+        if (lds_small < share) lds_small = share;
+        if (lds_small > (size_t)64 * 1024) lds_small = (size_t)64 * 1024;
+        b.lds_entries = (uint32_t)(lds_small / 4);
         // the spill variant costs the searches that never spill 1-5 % (a uniform branch per hop in the
         // hash probe): the caller passes the tables only when earlier launches at this ef needed them
         if (a.spill) {
             if (a.g.metric == 0)
-                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 3, true, FILT>), dim3(a.nq), dim3(64), lds_small, stream, a);
+                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 3, true, FILT>), dim3(a.nq), dim3(64), lds_small, stream, b);
             else
-                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 3, false, FILT>), dim3(a.nq), dim3(64), lds_small, stream, a);
+                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 3, false, FILT>), dim3(a.nq), dim3(64), lds_small, stream, b);
         } else if (a.g.metric == 0)
-            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 0, true, FILT>), dim3(a.nq), dim3(64), lds_small, stream, a);
+            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 0, true, FILT>), dim3(a.nq), dim3(64), lds_small, stream, b);
         else
-            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 0, false, FILT>), dim3(a.nq), dim3(64), lds_small, stream, a);
+            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 0, false, FILT>), dim3(a.nq), dim3(64), lds_small, stream, b);
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) {

@@ -126,8 +126,16 @@ __device__ __forceinline__ uint32_t score_nodes(const DevGraph& g, const f32x4 (
         f32x4 x[GPB][NCH];
 #pragma unroll
         for (int b = 0; b < GPB; ++b) {
+            // Rows beyond m are never loaded and their lanes' results never used (every caller masks lanes >= m), so
+            // their registers may hold anything: the empty asm makes them "written" without the 4 NCH v_mov per group
+            // that zero-filling costs on every call (64 of the ~430 vector instructions of a hop at d = 128).
+            // (chunks that reach past the row length - NCH is a power of two, the row a multiple of 32 floats - are
+            // not, or not fully, loaded in real rows either: those start from zero; wave-uniform per chunk)
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) x[b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NCH; ++j) {
+                asm volatile("" : "=v"(x[b][j]));
+                if ((uint32_t)(64 * (j + 1)) > vstride) x[b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             if (4u * (base + b) + (uint32_t)grp < m) {
                 const float* row = g.vecs + (size_t)nid[b] * vstride + 4 * t;
 #pragma unroll
