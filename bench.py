@@ -119,22 +119,30 @@ class Dist:
             self.d.destroy_process_group()
 
 
-def timed_sharded_steps(sharding, hs, shared_q, k, steps, warmup, dd):
-    """W + K sharded steps; per-step ms split into search / all-gather / merge (HIP events on the
-    launch stream, mean over the K steps, max over ranks) and the wall time of the K steps."""
+def timed_sharded_steps(sharding, hs, shared_q, k, steps, warmup, dd, comm=None):
+    """W + K sharded steps.  The timed step is ONE call of the C-ABI entry point
+    (vdb_sharded_search_batch_device: shard search + grouped ncclAllGather + merge on one stream) when an
+    RCCL communicator exists, else the torch.distributed spelling of it (gloo rehearsal).  The split into
+    search / all-gather / merge comes from a second loop of the torch spelling with HIP events between
+    the stages (mean over the K steps, max over ranks)."""
     import torch
+    step = (lambda: comm.sharded_search(hs, shared_q, k)) if comm is not None else (lambda: sharding.sharded_search(hs, shared_q, k))
     for _ in range(warmup):
-        sharding.sharded_search(hs, shared_q, k)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+        step()
     dd.barrier()
     t0 = time.perf_counter()
-    for e in ev:
-        out = sharding.sharded_search(hs, shared_q, k, events=e)
+    for _ in range(steps):
+        out = step()
     dd.barrier()
     wall = dd.reduce(time.perf_counter() - t0)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+    for e in ev:
+        sharding.sharded_search(hs, shared_q, k, events=e)
+    dd.barrier()
     parts = [float(np.mean([e[i].elapsed_time(e[i + 1]) for e in ev])) for i in range(3)]
     parts = [dd.reduce(p) for p in parts]
-    return wall, {"search": round(parts[0], 4), "all_gather": round(parts[1], 4), "merge": round(parts[2], 4)}, out
+    return wall, {"search": round(parts[0], 4), "all_gather": round(parts[1], 4), "merge": round(parts[2], 4),
+                  "timed_step": "vdb_sharded_search_batch_device (C-ABI, RCCL)" if comm is not None else "torch.distributed spelling"}, out
 
 
 def main() -> None:
@@ -312,8 +320,14 @@ def run_hnsw(args, dd, rank, local_rank, world, dev, cores, threads):
         # rank 0's ground truth is for its own batch == seed 2 == the shared batch
         srec = datasets.recall_at_k(ml.cpu().numpy().view(np.uint64), gt) if rank == 0 else 0.0
         log(f"rank {rank}: sharded search + all-gather + merge ok" + (f", recall@{k} {srec:.4f}" if rank == 0 else ""))
-        wall, split, _ = timed_sharded_steps(sharding, hs, shared_q, k, args.steps, args.warmup, dd)
-        ranks = dd.gather_objects({"rank": rank, "device": torch.cuda.current_device(), "host": os.uname().nodename})
+        comm = None if dd.rehearsal else sharding.Communicator.from_torch(local_rank)
+        if comm is not None:   # the C entry point returns what the torch spelling returned
+            cd, cl = comm.sharded_search(hs, shared_q, k)
+            torch.cuda.synchronize()
+            assert torch.equal(cl, ml) and torch.equal(cd, md), "vdb_sharded_search_batch_device differs from the torch.distributed path"
+        wall, split, _ = timed_sharded_steps(sharding, hs, shared_q, k, args.steps, args.warmup, dd, comm)
+        ranks = dd.gather_objects({"rank": rank, "device": torch.cuda.current_device(), "host": os.uname().nodename,
+                                   "rccl_rank": comm.rank if comm else None, "rccl_size": comm.n_ranks if comm else None})
         sharded = {"queries_per_s": round(args.nq * args.steps / wall, 1), "ms_per_step": round(wall / args.steps * 1e3, 4),
                    "ms_split_max_over_ranks": split, "recall_at_k": round(srec, 4),
                    "shards": world, "rows_per_shard": per, "ef": chosen, "shard_build_seconds": round(shard_build_s, 1),
@@ -560,7 +574,12 @@ def run_sharded_workload(args, dd, rank, local_rank, world, dev, cores, threads)
     torch.cuda.synchronize()
     recall = datasets.recall_at_k(ml.cpu().numpy().view(np.uint64), truth)
     log(f"rank {rank}: shard graph on the device in {build_s:.1f}s ({hs.device_bytes() / 1e9:.2f} GB); ef={ef} recall@{k} {recall:.4f}")
-    wall, split, _ = timed_sharded_steps(sharding, hs, dq, k, args.steps, args.warmup, dd)
+    comm = None
+    if world > 1 and not dd.rehearsal:
+        comm = sharding.Communicator.from_torch(local_rank)
+    elif world == 1:
+        comm = sharding.Communicator(sharding.Communicator.unique_id(), 1, 0, local_rank)
+    wall, split, _ = timed_sharded_steps(sharding, hs, dq, k, args.steps, args.warmup, dd, comm)
     _, _, st = hs.search_batch(dq, k, stats=True)
     st = st.cpu().numpy().view(np.uint32).astype(np.int64)
     alg_bytes = int((st[:, 0] * 4 * dim + st[:, 1] * 4 * (2 * args.M + 1) + st[:, 2] * 4 * (args.M + 1)).sum()

@@ -207,6 +207,30 @@ int vdb_bf_search_batch(const vdb_bruteforce* bf, const float* queries, size_t n
 int vdb_merge_topk_device(const float* d_dist, const uint64_t* d_label, size_t n_lists, size_t nq, size_t k,
                           float* d_out_dist, uint64_t* d_out_label, void* stream);
 
+/* ---- base-set sharding over the GPUs of a node (no reference counterpart) -----------
+ *
+ * One process (or thread) per GPU, each holding one shard: an independent HierarchicalNSW over a
+ * contiguous range of the base rows whose labels are the global row ids.  Every rank calls
+ * vdb_sharded_search_batch_device with the SAME query batch; the per-rank [nq][k] result lists are
+ * exchanged with ncclAllGather over RCCL (xGMI inside a node) and merged on every rank.  RCCL is bound at
+ * run time (dlopen of librccl.so.1): a process that never shards does not need it. */
+typedef struct vdb_comm vdb_comm;
+#define VDB_COMM_ID_BYTES 128
+/* ncclGetUniqueId on ONE rank; ship the 128 bytes to the others by any means (file, socket, MPI, ...). */
+int vdb_comm_unique_id(void* id128);
+/* ncclCommInitRank: collective over the n_ranks callers; `device` is the GPU this rank's shard lives on. */
+int vdb_comm_create(vdb_comm** out, const void* id128, int n_ranks, int rank, int device);
+/* The same around a communicator the caller already has (an ncclComm_t); it is not destroyed by vdb_comm_free. */
+int vdb_comm_wrap(vdb_comm** out, void* nccl_comm, int device);
+void vdb_comm_free(vdb_comm* comm);
+int vdb_comm_size(const vdb_comm* comm);
+int vdb_comm_rank(const vdb_comm* comm);
+/* searchKnn over the whole sharded base set: this rank's vdb_search_batch_device on `shard`, one grouped
+ * ncclAllGather of the [nq][k] distance and label lists, vdb_merge_topk_device - all on `stream`, no host
+ * synchronisation.  Outputs as vdb_search_batch_device, identical on every rank.  n_ranks * k <= 5461. */
+int vdb_sharded_search_batch_device(const vdb_index* shard, vdb_comm* comm, const float* d_queries, size_t nq, size_t k,
+                                    float* d_out_dist, uint64_t* d_out_label, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

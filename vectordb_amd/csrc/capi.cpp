@@ -2,6 +2,8 @@
 // index, and the enqueueing of the gfx950 kernels.  No CPU search lives here: every search
 // entry point runs the kernels or fails.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is bound at run time (rccl_api below)
 
 #include <algorithm>
 #include <atomic>
@@ -1256,6 +1258,178 @@ int vdb_bf_search_batch(const vdb_bruteforce* bf, const float* queries, size_t n
         VDB_HIP(hipStreamSynchronize(nullptr));
         VDB_HIP(hipMemcpy(out_dist, st.dist.p, nq * k * 4, hipMemcpyDeviceToHost));
         VDB_HIP(hipMemcpy(out_label, st.label.p, nq * k * 8, hipMemcpyDeviceToHost));
+        return (int)VDB_OK;
+    });
+}
+
+// ---- base-set sharding over RCCL ------------------------------------------------------------
+
+}  // extern "C"
+
+namespace {
+
+// RCCL is bound with dlopen at the first use: a process that never shards needs no librccl, and one that has
+// PyTorch loaded gets PyTorch's copy (same SONAME) instead of a second one.
+struct RcclApi {
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclCommCount) comm_count = nullptr;
+    decltype(&ncclCommUserRank) comm_user_rank = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    std::string error;
+};
+
+const RcclApi& rccl_api() {
+    static const RcclApi api = [] {
+        RcclApi a;
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) {
+            a.error = std::string("RCCL is not loadable (librccl.so.1): ") + (dlerror() ? dlerror() : "?");
+            return a;
+        }
+        auto bind = [&](auto& fn, const char* sym) {
+            fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(h, sym));
+            if (!fn && a.error.empty()) a.error = std::string("RCCL symbol missing: ") + sym;
+        };
+        bind(a.get_unique_id, "ncclGetUniqueId");
+        bind(a.comm_init_rank, "ncclCommInitRank");
+        bind(a.comm_destroy, "ncclCommDestroy");
+        bind(a.comm_count, "ncclCommCount");
+        bind(a.comm_user_rank, "ncclCommUserRank");
+        bind(a.all_gather, "ncclAllGather");
+        bind(a.group_start, "ncclGroupStart");
+        bind(a.group_end, "ncclGroupEnd");
+        bind(a.error_string, "ncclGetErrorString");
+        return a;
+    }();
+    if (!api.error.empty()) throw DeviceError(api.error);
+    return api;
+}
+
+#define VDB_RCCL(call)                                                                                         \
+    do {                                                                                                       \
+        ncclResult_t r_ = (call);                                                                              \
+        if (r_ != ncclSuccess) throw DeviceError(std::string(#call) + ": " + rccl_api().error_string(r_));       \
+    } while (0)
+
+}  // namespace
+
+struct vdb_comm {
+    ncclComm_t comm = nullptr;
+    bool owned = false;
+    int n_ranks = 0, rank = 0, device = -1;
+    std::mutex lock;
+    DevBuf my_dist, my_label, all_dist, all_label;  // [nq][k] and [n_ranks][nq][k], grow only
+    ~vdb_comm() {
+        if (device >= 0) {
+            try {
+                DeviceGuard g(device);
+                (void)hipDeviceSynchronize();
+                my_dist.release();
+                my_label.release();
+                all_dist.release();
+                all_label.release();
+                if (owned && comm) (void)rccl_api().comm_destroy(comm);
+            } catch (...) {
+            }
+        }
+    }
+};
+
+extern "C" {
+
+int vdb_comm_unique_id(void* id128) {
+    return guarded([&] {
+        if (!id128) throw std::invalid_argument("null buffer");
+        ncclUniqueId id;
+        VDB_RCCL(rccl_api().get_unique_id(&id));
+        static_assert(sizeof(id) == VDB_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+        std::memcpy(id128, &id, sizeof(id));
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_comm_create(vdb_comm** out, const void* id128, int n_ranks, int rank, int device) {
+    return guarded([&] {
+        if (!out || !id128) throw std::invalid_argument("null argument");
+        if (n_ranks < 1 || rank < 0 || rank >= n_ranks) throw std::invalid_argument("rank outside 0 .. n_ranks-1");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw DeviceError("no HIP device visible");
+        if (device < 0 || device >= ndev) throw std::invalid_argument("device ordinal out of range");
+        std::unique_ptr<vdb_comm> c(new vdb_comm);
+        DeviceGuard guard(device);
+        ncclUniqueId id;
+        std::memcpy(&id, id128, sizeof(id));
+        VDB_RCCL(rccl_api().comm_init_rank(&c->comm, n_ranks, id, rank));
+        c->owned = true;
+        c->n_ranks = n_ranks;
+        c->rank = rank;
+        c->device = device;
+        *out = c.release();
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_comm_wrap(vdb_comm** out, void* nccl_comm, int device) {
+    return guarded([&] {
+        if (!out || !nccl_comm) throw std::invalid_argument("null argument");
+        std::unique_ptr<vdb_comm> c(new vdb_comm);
+        c->comm = (ncclComm_t)nccl_comm;
+        VDB_RCCL(rccl_api().comm_count(c->comm, &c->n_ranks));
+        VDB_RCCL(rccl_api().comm_user_rank(c->comm, &c->rank));
+        c->device = device;
+        *out = c.release();
+        return (int)VDB_OK;
+    });
+}
+
+void vdb_comm_free(vdb_comm* c) { delete c; }
+int vdb_comm_size(const vdb_comm* c) { return c ? c->n_ranks : 0; }
+int vdb_comm_rank(const vdb_comm* c) { return c ? c->rank : -1; }
+
+int vdb_sharded_search_batch_device(const vdb_index* shard, vdb_comm* comm, const float* d_queries, size_t nq, size_t k,
+                                    float* d_out_dist, uint64_t* d_out_label, void* stream_) {
+    return guarded([&] {
+        if (!shard || !comm) throw std::invalid_argument("null argument");
+        if (nq == 0) return (int)VDB_OK;
+        if (!d_queries || !d_out_dist || !d_out_label) throw std::invalid_argument("null buffer");
+        if (k == 0) throw std::invalid_argument("k must be > 0");
+        if ((size_t)comm->n_ranks * k > 5461) throw std::invalid_argument("sharded search: n_ranks * k must be at most 5461");
+        if (shard->device != comm->device) throw std::invalid_argument("the shard and the communicator are on different devices");
+        hipStream_t stream = (hipStream_t)stream_;
+        DeviceGuard guard(comm->device);
+        std::unique_lock<std::mutex> lock(comm->lock);
+        const size_t per = nq * k, G = (size_t)comm->n_ranks;
+        if (comm->my_dist.bytes < per * 4 || comm->all_dist.bytes < G * per * 4) {
+            VDB_HIP(hipStreamSynchronize(stream));  // an earlier call may still be using the old buffers
+            comm->my_dist.reserve(per * 4);
+            comm->my_label.reserve(per * 8);
+            comm->all_dist.reserve(G * per * 4);
+            comm->all_label.reserve(G * per * 8);
+        }
+        // 1. this rank's shard (hnsw_core.hpp:1107-1159 on the sub-graph)
+        int rc = search_device(const_cast<vdb_index*>(shard), d_queries, nq, k, nullptr, (float*)comm->my_dist.p,
+                               (uint64_t*)comm->my_label.p, nullptr, stream, nullptr);
+        if (rc != VDB_OK) return rc;
+        // 2. the one exchange step: every rank's [nq][k] lists to every rank, both tensors in one group
+        const RcclApi& api = rccl_api();
+        VDB_RCCL(api.group_start());
+        VDB_RCCL(api.all_gather(comm->my_dist.p, comm->all_dist.p, per, ncclFloat32, comm->comm, stream));
+        VDB_RCCL(api.all_gather(comm->my_label.p, comm->all_label.p, per, ncclUint64, comm->comm, stream));
+        VDB_RCCL(api.group_end());
+        // 3. G ascending lists -> the k smallest (dist, label), on every rank
+        std::string err;
+        rc = launch_merge_topk((const float*)comm->all_dist.p, (const uint64_t*)comm->all_label.p, (uint32_t)G, (uint32_t)nq,
+                               (uint32_t)k, d_out_dist, d_out_label, stream, &err);
+        if (rc != 0) return set_error(rc, err);
         return (int)VDB_OK;
     });
 }

@@ -42,9 +42,64 @@ def build_shard(base: np.ndarray, world: int, rank: int, metric: int, M: int = 1
     return h
 
 
+class Communicator:
+    """vdb_comm (include/vdb_index.h): an RCCL communicator over the ranks that hold the shards, made
+    from a 128-byte id that rank 0 draws and the launcher ships to the others.  ``Communicator.from_torch``
+    ships it through an initialised torch.distributed group (any backend: it is 128 bytes)."""
+
+    def __init__(self, unique_id: bytes, n_ranks: int, rank: int, device: int):
+        import ctypes as C
+
+        from . import _lib
+        self._l = _lib.lib()
+        self._h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _lib.check(self._l.vdb_comm_create(C.byref(self._h), buf, n_ranks, rank, device))
+        self.n_ranks, self.rank, self.device = n_ranks, rank, device
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+
+        from . import _lib
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.lib().vdb_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_torch(cls, device: int) -> "Communicator":
+        import torch.distributed as td
+        box = [cls.unique_id() if td.get_rank() == 0 else None]
+        td.broadcast_object_list(box, src=0)
+        return cls(box[0], td.get_world_size(), td.get_rank(), device)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._l.vdb_comm_free(h)
+            self._h = None
+
+    def sharded_search(self, shard_index, queries, k: int):
+        """vdb_sharded_search_batch_device: shard search + grouped ncclAllGather + merge, one C call,
+        everything on torch's current stream.  ``queries``: the SAME CUDA batch on every rank."""
+        import torch
+
+        from . import _lib
+        q = queries.contiguous()
+        nq = q.shape[0]
+        od = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        ol = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+        _lib.check(self._l.vdb_sharded_search_batch_device(shard_index._h, self._h, q.data_ptr(), nq, k, od.data_ptr(),
+                                                           ol.data_ptr(), stream))
+        return od, ol
+
+
 def all_gather_results(dist, label):
     """[nq, k] per rank -> [world, nq, k] on every rank (torch tensors; RCCL on GPU tensors,
-    gloo on CPU tensors in the tests).  One collective per tensor."""
+    gloo on CPU tensors in the tests).  One collective per tensor.  This is the torch.distributed spelling
+    of the exchange step, kept for the CPU (gloo) tests, for bench.py's per-stage timing and for callers who
+    already live in torch; ``Communicator.sharded_search`` is the C-ABI one."""
     import torch
     import torch.distributed as td
 
