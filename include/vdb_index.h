@@ -200,6 +200,18 @@ int vdb_bf_search_batch_device(const vdb_bruteforce* bf, const float* d_queries,
 int vdb_bf_search_batch(const vdb_bruteforce* bf, const float* queries, size_t nq, size_t k, int precision,
                         float* out_dist, uint64_t* out_label);
 
+/* SearchKNN(query, K, filter), bruteforce.hpp:147-184 with a BaseFilterFunctor (hnswlib.hpp:64-68).  The functor's
+ * verdicts cross the ABI as a bitmap over ROWS in storage order (vdb_bf_labels lists the labels to call it on):
+ * bit (i % 32) of word i / 32 set = accepted; ceil(count / 32) words.  Always the exact scan (results as
+ * VDB_BF_FP32).  The reference's filtered scan is order dependent - a row beyond the first K is only considered
+ * when its distance is at or below the worst ACCEPTED row of the first K (:163-167) - and that is reproduced. */
+int vdb_bf_search_batch_device_filtered(const vdb_bruteforce* bf, const float* d_queries, size_t nq, size_t k,
+                                        const uint32_t* d_allow, float* d_out_dist, uint64_t* d_out_label, void* stream);
+int vdb_bf_search_batch_filtered(const vdb_bruteforce* bf, const float* queries, size_t nq, size_t k, const uint32_t* allow,
+                                 float* out_dist, uint64_t* out_label);
+/* The label of every stored row, in storage order (bruteforce.hpp:156-157); cap >= count. */
+int vdb_bf_labels(const vdb_bruteforce* bf, uint64_t* out, size_t cap);
+
 /* ---- shard merge (no reference counterpart) --------------------------- */
 
 /* Merge G per-shard result lists into one: inputs [G][nq][k] (each row ascending, padded

@@ -57,5 +57,18 @@ int main(int argc, char** argv) {
         auto res = loaded.SearchKNNCloserFirst(x.data() + q * dim, 5, &mod3);
         for (auto& p : res) std::printf("%zu %a\n", p.second, p.first);
     }
+    // BruteforceSearch::SearchKNN with and without a functor (bruteforce.hpp:147-184)
+    BruteforceSearch bf(&space, n);
+    for (size_t i = 0; i < n; ++i) bf.addPoint(x.data() + i * dim, 1000 + i);
+    std::puts("bruteforce");
+    for (size_t q = 0; q < 10; ++q) {
+        auto res = bf.SearchKNNCloserFirst(x.data() + q * dim, 5);
+        for (auto& p : res) std::printf("%zu %a\n", p.second, p.first);
+    }
+    std::puts("bruteforce filtered");
+    for (size_t q = 0; q < 10; ++q) {
+        auto res = bf.SearchKNNCloserFirst(x.data() + q * dim, 7, &mod3);
+        for (auto& p : res) std::printf("%zu %a\n", p.second, p.first);
+    }
     return 0;
 }

@@ -195,3 +195,29 @@ def test_mfma_bf16_paths(orc, dim, metric):
     exact = np.array([[orc.distance(metric, orc.TREE64, q[i], x[int(l1[i, j])]) for j in range(k)] for i in range(0, 200, 20)])
     scale = np.abs(exact).max()
     np.testing.assert_allclose(d1[0:200:20], exact, atol=0.02 * scale)
+
+
+@pytest.mark.parametrize("n,dim,metric,k,mod,keep", [(5000, 64, vi.L2, 10, 3, 1), (9000, 48, vi.IP, 25, 7, 0), (300, 16, vi.L2, 40, 2, 1),
+                                                      (6000, 24, vi.L2, 10, 1000, 999), (20, 8, vi.L2, 32, 2, 0)])
+def test_bruteforce_with_a_filter(orc, n, dim, metric, k, mod, keep):
+    """bruteforce.hpp:154-181 with a BaseFilterFunctor.  The reference's filtered scan is order dependent (a row
+    beyond the first K counts only at or below the worst accepted row of the first K), and so is the oracle's
+    restatement; the device answer must equal it bit for bit - also when the filter accepts almost nothing
+    (mod 1000), when K > n, and through the one-query spelling."""
+    x = datasets.uniform(n, dim, 121)
+    q = datasets.uniform(33, dim, 122)
+    labels = np.random.default_rng(7).permutation(n).astype(np.uint64) + 17
+    space = vi.L2Space(dim) if metric == vi.L2 else vi.InnerProductSpace(dim)
+    b = vi.BruteforceSearch(space, n)
+    b.add_items(x, labels)
+    b.to_device(0)
+    d, l = b.search_batch(q, k, filter=lambda lab: lab % mod == keep)
+    ob = orc.OracleBruteforce(metric, dim, n, mode=orc.TREE64)
+    ob.add(x, labels)
+    r = ob.search(q, k, filter_mod=mod, filter_keep=keep)
+    np.testing.assert_array_equal(l, r["label"].astype(np.uint64))
+    np.testing.assert_array_equal(d.view(np.uint32), r["dist"].view(np.uint32))
+    found = l[l != np.uint64(2**64 - 1)]
+    assert (found % mod == keep).all()
+    one = b.SearchKNNCloserFirst(q[0], k, filter=lambda lab: lab % mod == keep)
+    assert [lab for _, lab in one] == [int(v) for v in l[0] if v != np.uint64(2**64 - 1)]

@@ -32,7 +32,9 @@ def test_cpp_wrapper_search_matches_oracle(demo, orc, tmp_path):
     path = str(tmp_path / "i.bin")
     r = subprocess.run([demo, "gpu", path], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    bare_out, filt_out = r.stdout.strip().split("filtered\n")
+    hnsw_out, bf_out, bf_filt_out = r.stdout.strip().split("bruteforce")
+    bare_out, filt_out = hnsw_out.split("filtered\n")
+    bf_filt_out = bf_filt_out.replace(" filtered\n", "")
     parse = lambda text: [(int(a), float.fromhex(b)) for a, b in (line.split() for line in text.strip().splitlines())]
     got, got_f = parse(bare_out), parse(filt_out)
     o = orc.OracleHNSW.load(path, orc.L2, 24, mode=orc.TREE64)
@@ -51,3 +53,12 @@ def test_cpp_wrapper_search_matches_oracle(demo, orc, tmp_path):
     res = o.search(x[:10], 5, filter_mod=3, filter_keep=1)
     want_f = [(int(l), float(d)) for ls, ds, c in zip(res["label"], res["dist"], res["count"]) for l, d in zip(ls[:c], ds[:c])]
     assert got_f == want_f and all(l % 3 == 1 and l >= 10 for l, _ in got_f)
+    # third part: BruteforceSearch over the same rows with labels 1000 + i, bare (k=5) and with the functor (k=7)
+    ob = orc.OracleBruteforce(orc.L2, 24, 500, mode=orc.TREE64)
+    ob.add(x, np.arange(500, dtype=np.uint64) + 1000)
+    res = ob.search(x[:10], 5)
+    assert parse(bf_out) == [(int(l), float(d)) for ls, ds in zip(res["label"], res["dist"]) for l, d in zip(ls, ds)]
+    res = ob.search(x[:10], 7, filter_mod=3, filter_keep=1)
+    none = np.uint64(2**64 - 1)
+    want_bf = [(int(l), float(d)) for ls, ds in zip(res["label"].astype(np.uint64), res["dist"]) for l, d in zip(ls, ds) if l != none]
+    assert parse(bf_filt_out) == want_bf and all(l % 3 == 1 for l, _ in want_bf)

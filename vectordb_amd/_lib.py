@@ -68,6 +68,9 @@ SIGNATURES = {
     "vdb_bf_to_device": (C.c_int, [_vp, C.c_int]),
     "vdb_bf_search_batch_device": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int, _vp, _vp, _vp]),
     "vdb_bf_search_batch": (C.c_int, [_vp, _f32p, C.c_size_t, C.c_size_t, C.c_int, _f32p, _u64p]),
+    "vdb_bf_search_batch_device_filtered": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp, _vp, _vp]),
+    "vdb_bf_search_batch_filtered": (C.c_int, [_vp, _f32p, C.c_size_t, C.c_size_t, _u32p, _f32p, _u64p]),
+    "vdb_bf_labels": (C.c_int, [_vp, _u64p, C.c_size_t]),
     "vdb_comm_unique_id": (C.c_int, [_vp]),
     "vdb_comm_create": (C.c_int, [C.POINTER(_vp), _vp, C.c_int, C.c_int, C.c_int]),
     "vdb_comm_wrap": (C.c_int, [C.POINTER(_vp), _vp, C.c_int]),

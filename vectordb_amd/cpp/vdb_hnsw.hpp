@@ -209,10 +209,23 @@ public:
     }
     std::priority_queue<std::pair<float, labeltype>> SearchKNN(const void* query, size_t k,
                                                                BaseFilterFunctor* filter = nullptr) const override {
-        if (filter) throw std::runtime_error("filtered search is not on the device path yet");
         std::vector<float> d(k);
         std::vector<uint64_t> l(k);
-        searchKnnBatch(static_cast<const float*>(query), 1, k, d.data(), l.data());
+        if (filter) {  // bruteforce.hpp:158-161, :170-173: the functor's verdicts cross the ABI as a bitmap over rows
+            const size_t n = vdb_bf_count(bf_);
+            std::vector<uint64_t> labels(n);
+            vdb_check(vdb_bf_labels(bf_, labels.data(), n));
+            std::vector<uint32_t> allow((n + 31) / 32 + 1, 0u);
+            for (size_t i = 0; i < n; ++i)
+                if ((*filter)((labeltype)labels[i])) allow[i >> 5] |= 1u << (i & 31);
+            if (dirty_) {
+                vdb_check(vdb_bf_to_device(bf_, device_));
+                dirty_ = false;
+            }
+            vdb_check(vdb_bf_search_batch_filtered(bf_, static_cast<const float*>(query), 1, k, allow.data(), d.data(), l.data()));
+        } else {
+            searchKnnBatch(static_cast<const float*>(query), 1, k, d.data(), l.data());
+        }
         std::priority_queue<std::pair<float, labeltype>> out;
         for (size_t i = 0; i < k; ++i)
             if (l[i] != std::numeric_limits<uint64_t>::max()) out.emplace(d[i], (labeltype)l[i]);

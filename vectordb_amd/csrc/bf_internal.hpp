@@ -21,6 +21,7 @@ struct CompactArgs {
     const float* cert;       // nullable (final pass): the result of slot q is proven exact iff its
                              // k-th distance is < cert[q]; otherwise q is appended to redo
     uint32_t* redo;          // [0] = count, [1 + i] = query ids to re-run exactly
+    const uint32_t* tau_floor;  // nullable [nq]: the threshold a query keeps while it has fewer than k results (filtered scan)
     uint32_t* overflow;      // nullable [nq]: set when a buffer received more than `cap` candidates
                              // (some were lost): such a slot is never proven exact
 };

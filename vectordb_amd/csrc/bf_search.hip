@@ -65,6 +65,12 @@ struct ScanArgs {
     uint64_t* entries;              // [nq][cap]  ord(dist) << 32 | row
     const uint32_t* qmap;           // nullable: slot i scans query qmap[i] (re-run of flagged queries)
     const uint32_t* nq_dev;         // nullable: number of live slots, read on the device
+    const uint32_t* allow;          // nullable: bit (row % 32) of word row / 32 = the filter accepts the row's label
+                                    // (BaseFilterFunctor, bruteforce.hpp:158-161, :170-173)
+    const uint32_t* first_allowed;  // nullable, filtered scans: the first row the filter accepts (bf_first_allowed)
+    uint32_t k_first;               // the first K rows (bruteforce.hpp:154)
+    uint32_t only_first_allowed;    // 1: scan that one row alone, and only when it lies beyond the first K;
+                                    // 0: the sweep - skip it there, it has been taken already
 };
 
 constexpr int kScanRowsPerBlock = 256;  // 4 waves x 16 steps x 4 rows
@@ -89,12 +95,23 @@ __global__ __launch_bounds__(256) void bf_scan_exact(ScanArgs a) {
     __syncthreads();
 
     const bool is_l2 = a.metric == 0;
-    const uint32_t block_row = a.row_lo + blockIdx.x * kScanRowsPerBlock;
+    uint32_t row_lo = a.row_lo, row_hi = a.row_hi, taken = 0xFFFFFFFFu;
+    if (a.first_allowed) {
+        const uint32_t r0 = *a.first_allowed;
+        if (a.only_first_allowed) {
+            if (r0 < a.k_first || r0 >= a.row_hi) return;  // among the first K, or no row is accepted at all
+            row_lo = r0;
+            row_hi = r0 + 1;
+        } else if (r0 >= a.k_first) {
+            taken = r0;
+        }
+    }
+    const uint32_t block_row = row_lo + blockIdx.x * kScanRowsPerBlock;
 #pragma unroll 1
     for (int step = 0; step < 16; ++step) {
         const uint32_t row = block_row + (uint32_t)((wave * 16 + step) * 4 + grp);
-        if (block_row + (uint32_t)((wave * 16 + step) * 4) >= a.row_hi) break;  // wave-uniform
-        const bool live = row < a.row_hi;
+        if (block_row + (uint32_t)((wave * 16 + step) * 4) >= row_hi) break;  // wave-uniform
+        const bool live = row < row_hi && row != taken;
         f32x4 x[NCH];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
@@ -130,7 +147,8 @@ __global__ __launch_bounds__(256) void bf_scan_exact(ScanArgs a) {
             s = s + dpp_f32<kDppMirror>(s);
             if (!is_l2) s = 1.0f - s;
             const uint32_t od = f2ord(s);
-            if (t == 0 && live && od <= s_tau[qi]) {  // bruteforce.hpp:167 `dist <= lastdist`
+            if (t == 0 && live && od <= s_tau[qi] &&  // bruteforce.hpp:167 `dist <= lastdist`, then the filter (:170)
+                (a.allow == nullptr || ((a.allow[row >> 5] >> (row & 31u)) & 1u) != 0u)) {
                 const uint32_t pos = atomicAdd(&a.count[q0 + qi], 1u);
                 if (pos < a.cap) a.entries[(size_t)(q0 + qi) * a.cap + pos] = ((uint64_t)od << 32) | row;
             }
@@ -208,7 +226,9 @@ __global__ __launch_bounds__(64) void bf_compact(CompactArgs a) {
         for (uint32_t i = lane; i < keep; i += 64) ent[i] = s_key[i];
         if (lane == 0) {
             a.count[q] = keep;
-            a.tau[q] = keep == k ? (uint32_t)(s_key[k - 1] >> 32) : 0xFFFFFFFFu;
+            // lastdist = the worst result once there are k of them (bruteforce.hpp:174-180); before that it is
+            // "no bound" without a filter, and with one what the first K rows left behind (tau_floor, bf_first_rows_bound)
+            a.tau[q] = keep == k ? (uint32_t)(s_key[k - 1] >> 32) : (a.tau_floor ? a.tau_floor[q] : 0xFFFFFFFFu);
         }
         return;
     }
@@ -244,6 +264,45 @@ __global__ __launch_bounds__(64) void bf_compact(CompactArgs a) {
         od[i] = __builtin_inff();
         ol[i] = ~0ull;
     }
+}
+
+// With a filter the reference's `lastdist` starts as the worst distance among the ACCEPTED rows of the first K
+// (bruteforce.hpp:154-163: `topResults.top().first`) and from then on is `topResults.top().first` after every row
+// at or below it (:177-180) - also while fewer than K results exist.  When none of the first K was accepted it
+// starts as the largest float, and the first accepted row of the sweep, whatever its distance, becomes the top
+// and with it the bound.  Either way a later row can only ever be a result when its distance is <= that first
+// bound: the answer is the K smallest (dist, label) among the accepted rows at or below it, not among all
+// accepted rows.  Restated: the first K rows - and the first accepted row, when it lies beyond them - are scanned
+// with an open threshold, this kernel turns what they appended into the bound, the sweep goes on.
+
+// The first row the filter accepts (0xFFFFFFFF when none): *out must start as 0xFFFFFFFF.
+__global__ __launch_bounds__(256) void bf_first_allowed(const uint32_t* allow, uint32_t n, uint32_t* out) {
+    const uint32_t words = (n + 31u) / 32u;
+    for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < words; w += gridDim.x * 256) {
+        uint32_t v = allow[w];
+        if (w == words - 1 && (n & 31u)) v &= (1u << (n & 31u)) - 1u;  // bits beyond the last row are not rows
+        if (v) {
+            atomicMin(out, w * 32u + (uint32_t)__builtin_ctz(v));
+            return;  // this thread's later words hold later rows
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bf_first_rows_bound(const uint32_t* count, const uint64_t* entries, uint32_t cap, uint32_t nq,
+                                                           uint32_t* tau, uint32_t* tau_floor) {
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const uint32_t c = count[q] < cap ? count[q] : cap;
+    uint32_t worst = 0xFFFFFFFFu;  // nothing accepted: std::numeric_limits<dist_t>::max() - everything passes
+    if (c) {
+        worst = 0;
+        for (uint32_t i = 0; i < c; ++i) {
+            const uint32_t d = (uint32_t)(entries[(size_t)q * cap + i] >> 32);
+            worst = d > worst ? d : worst;
+        }
+    }
+    tau[q] = worst;
+    tau_floor[q] = worst;
 }
 
 // ------------------------------------------------------------------ shard merge
@@ -298,12 +357,12 @@ hipError_t enqueue_bf_compact(const CompactArgs& c, hipStream_t stream) {
     return hipGetLastError();
 }
 
-size_t bf_exact_workspace_bytes(uint32_t nq) { return (size_t)nq * (8 + (size_t)kBfCap * 8); }
+size_t bf_exact_workspace_bytes(uint32_t nq) { return (size_t)nq * (8 + (size_t)kBfCap * 8) + (size_t)nq * 4 + 256; }
 
 int launch_bf_exact(const float* d_base, const uint64_t* d_labels, uint32_t n, uint32_t dim, uint32_t vstride,
                     int metric, const float* d_queries, uint32_t nq, uint32_t k, float* d_out_dist,
                     uint64_t* d_out_label, void* workspace, hipStream_t stream, std::string* err,
-                    const uint32_t* d_qmap, const uint32_t* d_nq_live) {
+                    const uint32_t* d_qmap, const uint32_t* d_nq_live, const uint32_t* d_allow) {
     if (nq == 0) return 0;
     if (k == 0 || k > kBfMaxK) {
         if (err) *err = "brute force: k must be in 1..1024";
@@ -336,6 +395,20 @@ int launch_bf_exact(const float* d_base, const uint64_t* d_labels, uint32_t n, u
     s.entries = entries;
     s.qmap = d_qmap;
     s.nq_dev = d_nq_live;
+    s.allow = d_allow;
+    uint32_t* tau_floor = reinterpret_cast<uint32_t*>(entries + (size_t)nq * kBfCap);
+    uint32_t* first_allowed = tau_floor + nq;
+    if (d_allow) {
+        if (e == hipSuccess) e = hipMemsetAsync(first_allowed, 0xFF, 4, stream);
+        if (e == hipSuccess) {
+            const uint32_t words = (n + 31u) / 32u;
+            const uint32_t blocks = words / 256u + 1u < 1024u ? words / 256u + 1u : 1024u;
+            hipLaunchKernelGGL(bf_first_allowed, dim3(blocks), dim3(256), 0, stream, d_allow, n, first_allowed);
+            e = hipGetLastError();
+        }
+        s.first_allowed = first_allowed;
+        s.k_first = k;
+    }
     const size_t scan_lds = (size_t)qt * vstride * 4 + (size_t)qt * 4;
 
     CompactArgs c{};
@@ -350,25 +423,44 @@ int launch_bf_exact(const float* d_base, const uint64_t* d_labels, uint32_t n, u
     c.out_label = d_out_label;
     c.qmap = d_qmap;
     c.nq_dev = d_nq_live;
+    c.tau_floor = d_allow ? tau_floor : nullptr;
 
     const uint32_t slab = kBfCap - k;
     const uint32_t nch = (vstride + 63u) / 64u;
+    auto scan = [&](uint32_t lo, uint32_t hi) {
+        s.row_lo = lo;
+        s.row_hi = hi;
+        const dim3 grid(s.only_first_allowed ? 1u : (hi - lo + kScanRowsPerBlock - 1) / kScanRowsPerBlock, (nq + qt - 1) / qt);
+        if (nch <= 1) launch_scan<1>(s, grid, scan_lds, stream);
+        else if (nch <= 2) launch_scan<2>(s, grid, scan_lds, stream);
+        else if (nch <= 4) launch_scan<4>(s, grid, scan_lds, stream);
+        else if (nch <= 8) launch_scan<8>(s, grid, scan_lds, stream);
+        else launch_scan<16>(s, grid, scan_lds, stream);
+        return hipGetLastError();
+    };
     uint32_t lo = 0;
+    bool first_rows = d_allow != nullptr;  // filtered: the first K rows alone, then their bound (bf_first_rows_bound)
     do {
-        const uint32_t hi = n - lo > slab ? lo + slab : n;
-        if (hi > lo && e == hipSuccess) {
-            s.row_lo = lo;
-            s.row_hi = hi;
-            const dim3 grid((hi - lo + kScanRowsPerBlock - 1) / kScanRowsPerBlock, (nq + qt - 1) / qt);
-            if (nch <= 1) launch_scan<1>(s, grid, scan_lds, stream);
-            else if (nch <= 2) launch_scan<2>(s, grid, scan_lds, stream);
-            else if (nch <= 4) launch_scan<4>(s, grid, scan_lds, stream);
-            else if (nch <= 8) launch_scan<8>(s, grid, scan_lds, stream);
-            else launch_scan<16>(s, grid, scan_lds, stream);
-            e = hipGetLastError();
-        }
+        uint32_t hi = n - lo > slab ? lo + slab : n;
+        if (first_rows) hi = n < k ? n : k;
+        if (hi > lo && e == hipSuccess) e = scan(lo, hi);
         lo = hi;
         c.final_pass = lo >= n ? 1 : 0;
+        if (first_rows && !c.final_pass) {
+            first_rows = false;
+            if (e == hipSuccess) {  // the first accepted row, when the first K hold none (one block of rows, row read on the device)
+                s.only_first_allowed = 1;
+                e = scan(0, n);
+                s.only_first_allowed = 0;
+            }
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(bf_first_rows_bound, dim3((nq + 255) / 256), dim3(256), 0, stream, count, entries, (uint32_t)kBfCap, nq,
+                                   tau, tau_floor);
+                e = hipGetLastError();
+            }
+            continue;  // nothing to compact: at most K entries so far
+        }
+        first_rows = false;
         if (e == hipSuccess) {
             e = enqueue_bf_compact(c, stream);
         }

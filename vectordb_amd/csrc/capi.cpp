@@ -1181,57 +1181,124 @@ int vdb_bf_to_device(vdb_bruteforce* bf, int device) {
     });
 }
 
-int vdb_bf_search_batch_device(const vdb_bruteforce* cbf, const float* d_queries, size_t nq, size_t k, int precision,
-                               float* d_out_dist, uint64_t* d_out_label, void* stream_) {
+}  // extern "C"
+
+namespace {
+
+// SearchKNN over a batch; d_allow = nullable device bitmap over ROWS (a BaseFilterFunctor's verdicts).
+int bf_search_device(vdb_bruteforce* bf, const float* d_queries, size_t nq, size_t k, int precision, const uint32_t* d_allow,
+                     float* d_out_dist, uint64_t* d_out_label, hipStream_t stream) {
+    if (!bf) throw std::invalid_argument("null index");
+    if (bf->device < 0) throw DeviceError("index is not on a device: call vdb_bf_to_device first");
+    if (bf->device_version != bf->host->version) throw DeviceError("index changed since vdb_bf_to_device: upload it again");
+    if (nq == 0) return (int)VDB_OK;
+    if (!d_queries || !d_out_dist || !d_out_label) throw std::invalid_argument("null buffer");
+    if (k == 0) throw std::invalid_argument("k must be > 0");
+    if (nq > 0x7FFFFFFFull) throw std::invalid_argument("batch too large");
+    if (precision != VDB_BF_FP32 && precision != VDB_BF_BF16 && precision != VDB_BF_BF16_RERANK)
+        throw std::invalid_argument("unknown brute-force precision");
+    if (k > kBfMaxK) throw Unsupported("brute force: k above 1024 is not supported by the device path");
+    // small problems and very large k go straight to the exact scan (same results, no setup cost); so does a
+    // filtered search: the reference's filtered scan depends on the row order (bf_search.hip, bf_first_rows_bound)
+    const bool exact_only = d_allow != nullptr || (precision == VDB_BF_FP32 && (bf->n < 4 * kBfMfmaCap || k + 32 > kBfMfmaCap / 2));
+    DeviceGuard guard(bf->device);
+    std::unique_lock<std::mutex> lock(bf->scratch_lock);
+    auto& ws = bf->scratch[stream];
+    if (!ws) ws.reset(new DevBuf);
+    const size_t need = exact_only ? bf_exact_workspace_bytes((uint32_t)nq) : bf_mfma_workspace_bytes((uint32_t)nq, bf->vstride, bf->kp64);
+    if (ws->bytes < need) {
+        if (ws->p) VDB_HIP(hipStreamSynchronize(stream));
+        ws->alloc(need);
+    }
+    std::string err;
+    int rc;
+    if (exact_only) {
+        rc = launch_bf_exact((const float*)bf->vecs.p, (const uint64_t*)bf->labels.p, bf->n, (uint32_t)bf->host->dim, bf->vstride,
+                             bf->host->metric, d_queries, (uint32_t)nq, (uint32_t)k, d_out_dist, d_out_label, ws->p, stream, &err,
+                             nullptr, nullptr, d_allow);
+    } else {
+        BfDeviceData d;
+        d.raw = (const float*)bf->vecs.p;
+        d.xc = (const float*)bf->xc.p;
+        d.xb = bf->xb.p;
+        d.nx = (const float*)bf->nx.p;
+        d.mu = (const float*)bf->mu.p;
+        d.stats = (const float*)bf->stats.p;
+        d.labels = (const uint64_t*)bf->labels.p;
+        d.n = bf->n;
+        d.dim = (uint32_t)bf->host->dim;
+        d.vstride = bf->vstride;
+        d.kp64 = bf->kp64;
+        d.metric = bf->host->metric;
+        rc = launch_bf_mfma(d, precision, d_queries, (uint32_t)nq, (uint32_t)k, d_out_dist, d_out_label, ws->p, stream, &err);
+    }
+    if (rc != 0) return set_error(rc, err);
+    return (int)VDB_OK;
+}
+
+int bf_search_host(vdb_bruteforce* bf, const float* queries, size_t nq, size_t k, int precision, const uint32_t* allow,
+                   float* out_dist, uint64_t* out_label) {
+    if (!bf) throw std::invalid_argument("null index");
+    if (bf->device < 0) throw DeviceError("index is not on a device: call vdb_bf_to_device first");
+    if (nq == 0) return (int)VDB_OK;
+    if (!queries || !out_dist || !out_label) throw std::invalid_argument("null buffer");
+    if (k == 0) throw std::invalid_argument("k must be > 0");
+    DeviceGuard guard(bf->device);
+    const size_t dim = bf->host->dim;
+    HostStage& st = bf->stage;
+    std::unique_lock<std::mutex> stage_guard(st.lock);
+    st.q.reserve(nq * dim * 4);
+    st.dist.reserve(nq * k * 4);
+    st.label.reserve(nq * k * 8);
+    VDB_HIP(hipMemcpy(st.q.p, queries, nq * dim * 4, hipMemcpyHostToDevice));
+    if (allow) {
+        const size_t words = ((size_t)bf->n + 31) / 32;
+        st.filter.reserve(std::max<size_t>(words, 1) * 4);
+        VDB_HIP(hipMemcpy(st.filter.p, allow, words * 4, hipMemcpyHostToDevice));
+    }
+    const int rc = bf_search_device(bf, (const float*)st.q.p, nq, k, precision, allow ? (const uint32_t*)st.filter.p : nullptr,
+                                    (float*)st.dist.p, (uint64_t*)st.label.p, nullptr);
+    if (rc != VDB_OK) return rc;
+    VDB_HIP(hipStreamSynchronize(nullptr));
+    VDB_HIP(hipMemcpy(out_dist, st.dist.p, nq * k * 4, hipMemcpyDeviceToHost));
+    VDB_HIP(hipMemcpy(out_label, st.label.p, nq * k * 8, hipMemcpyDeviceToHost));
+    return (int)VDB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vdb_bf_search_batch_device(const vdb_bruteforce* bf, const float* d_queries, size_t nq, size_t k, int precision,
+                               float* d_out_dist, uint64_t* d_out_label, void* stream) {
     return guarded([&] {
-        vdb_bruteforce* bf = const_cast<vdb_bruteforce*>(cbf);
-        if (!bf) throw std::invalid_argument("null index");
-        if (bf->device < 0) throw DeviceError("index is not on a device: call vdb_bf_to_device first");
-        if (bf->device_version != bf->host->version) throw DeviceError("index changed since vdb_bf_to_device: upload it again");
-        if (nq == 0) return (int)VDB_OK;
-        if (!d_queries || !d_out_dist || !d_out_label) throw std::invalid_argument("null buffer");
-        if (k == 0) throw std::invalid_argument("k must be > 0");
-        if (nq > 0x7FFFFFFFull) throw std::invalid_argument("batch too large");
-        if (precision != VDB_BF_FP32 && precision != VDB_BF_BF16 && precision != VDB_BF_BF16_RERANK)
-            throw std::invalid_argument("unknown brute-force precision");
-        if (k > kBfMaxK) throw Unsupported("brute force: k above 1024 is not supported by the device path");
-        // small problems and very large k go straight to the exact scan (same results, no setup cost)
-        const bool exact_only = precision == VDB_BF_FP32 && (bf->n < 4 * kBfMfmaCap || k + 32 > kBfMfmaCap / 2);
-        hipStream_t stream = (hipStream_t)stream_;
-        DeviceGuard guard(bf->device);
-        std::unique_lock<std::mutex> lock(bf->scratch_lock);
-        auto& ws = bf->scratch[stream];
-        if (!ws) ws.reset(new DevBuf);
-        const size_t need = exact_only ? bf_exact_workspace_bytes((uint32_t)nq)
-                                       : bf_mfma_workspace_bytes((uint32_t)nq, bf->vstride, bf->kp64);
-        if (ws->bytes < need) {
-            if (ws->p) VDB_HIP(hipStreamSynchronize(stream));
-            ws->alloc(need);
-        }
-        std::string err;
-        int rc;
-        if (exact_only) {
-            rc = launch_bf_exact((const float*)bf->vecs.p, (const uint64_t*)bf->labels.p, bf->n, (uint32_t)bf->host->dim,
-                                 bf->vstride, bf->host->metric, d_queries, (uint32_t)nq, (uint32_t)k, d_out_dist,
-                                 d_out_label, ws->p, stream, &err);
-        } else {
-            BfDeviceData d;
-            d.raw = (const float*)bf->vecs.p;
-            d.xc = (const float*)bf->xc.p;
-            d.xb = bf->xb.p;
-            d.nx = (const float*)bf->nx.p;
-            d.mu = (const float*)bf->mu.p;
-            d.stats = (const float*)bf->stats.p;
-            d.labels = (const uint64_t*)bf->labels.p;
-            d.n = bf->n;
-            d.dim = (uint32_t)bf->host->dim;
-            d.vstride = bf->vstride;
-            d.kp64 = bf->kp64;
-            d.metric = bf->host->metric;
-            rc = launch_bf_mfma(d, precision, d_queries, (uint32_t)nq, (uint32_t)k, d_out_dist, d_out_label, ws->p,
-                                stream, &err);
-        }
-        if (rc != 0) return set_error(rc, err);
+        return bf_search_device(const_cast<vdb_bruteforce*>(bf), d_queries, nq, k, precision, nullptr, d_out_dist, d_out_label,
+                                (hipStream_t)stream);
+    });
+}
+
+int vdb_bf_search_batch_device_filtered(const vdb_bruteforce* bf, const float* d_queries, size_t nq, size_t k, const uint32_t* d_allow,
+                                        float* d_out_dist, uint64_t* d_out_label, void* stream) {
+    return guarded([&] {
+        return bf_search_device(const_cast<vdb_bruteforce*>(bf), d_queries, nq, k, VDB_BF_FP32, d_allow, d_out_dist, d_out_label,
+                                (hipStream_t)stream);
+    });
+}
+
+int vdb_bf_search_batch_filtered(const vdb_bruteforce* bf, const float* queries, size_t nq, size_t k, const uint32_t* allow,
+                                 float* out_dist, uint64_t* out_label) {
+    return guarded([&] {
+        return bf_search_host(const_cast<vdb_bruteforce*>(bf), queries, nq, k, VDB_BF_FP32, allow, out_dist, out_label);
+    });
+}
+
+int vdb_bf_labels(const vdb_bruteforce* bf, uint64_t* out, size_t cap) {
+    return guarded([&] {
+        if (!bf || !out) throw std::invalid_argument("null argument");
+        HostBruteforce& h = *bf->host;
+        std::unique_lock<std::mutex> g(h.lock);
+        if (cap < h.count) throw std::invalid_argument("label buffer smaller than the element count");
+        for (size_t i = 0; i < h.count; ++i) std::memcpy(&out[i], h.data + i * h.stride + h.data_size, 8);
         return (int)VDB_OK;
     });
 }
@@ -1239,26 +1306,7 @@ int vdb_bf_search_batch_device(const vdb_bruteforce* cbf, const float* d_queries
 int vdb_bf_search_batch(const vdb_bruteforce* bf, const float* queries, size_t nq, size_t k, int precision,
                         float* out_dist, uint64_t* out_label) {
     return guarded([&] {
-        if (!bf) throw std::invalid_argument("null index");
-        if (bf->device < 0) throw DeviceError("index is not on a device: call vdb_bf_to_device first");
-        if (nq == 0) return (int)VDB_OK;
-        if (!queries || !out_dist || !out_label) throw std::invalid_argument("null buffer");
-        if (k == 0) throw std::invalid_argument("k must be > 0");
-        DeviceGuard guard(bf->device);
-        const size_t dim = bf->host->dim;
-        HostStage& st = const_cast<vdb_bruteforce*>(bf)->stage;
-        std::unique_lock<std::mutex> stage_guard(st.lock);
-        st.q.reserve(nq * dim * 4);
-        st.dist.reserve(nq * k * 4);
-        st.label.reserve(nq * k * 8);
-        VDB_HIP(hipMemcpy(st.q.p, queries, nq * dim * 4, hipMemcpyHostToDevice));
-        const int rc = vdb_bf_search_batch_device(bf, (const float*)st.q.p, nq, k, precision, (float*)st.dist.p,
-                                                  (uint64_t*)st.label.p, nullptr);
-        if (rc != VDB_OK) return rc;
-        VDB_HIP(hipStreamSynchronize(nullptr));
-        VDB_HIP(hipMemcpy(out_dist, st.dist.p, nq * k * 4, hipMemcpyDeviceToHost));
-        VDB_HIP(hipMemcpy(out_label, st.label.p, nq * k * 8, hipMemcpyDeviceToHost));
-        return (int)VDB_OK;
+        return bf_search_host(const_cast<vdb_bruteforce*>(bf), queries, nq, k, precision, nullptr, out_dist, out_label);
     });
 }
 

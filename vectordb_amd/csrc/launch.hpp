@@ -80,12 +80,13 @@ constexpr uint32_t kBfMaxK = 1024;
 // Bytes of scratch the exact scan needs for nq queries.
 size_t bf_exact_workspace_bytes(uint32_t nq);
 
+// d_allow: nullable bitmap over rows (a BaseFilterFunctor's verdicts): the reference's filtered scan, bruteforce.hpp:154-181.
 // Exact k-NN of nq queries over base[n][vstride] (rows zero-padded beyond dim): enqueues the
 // slab sweep on `stream`.  Outputs ascending (dist, label), padded with (+inf, UINT64_MAX).
 int launch_bf_exact(const float* d_base, const uint64_t* d_labels, uint32_t n, uint32_t dim, uint32_t vstride,
                     int metric, const float* d_queries, uint32_t nq, uint32_t k, float* d_out_dist,
                     uint64_t* d_out_label, void* workspace, hipStream_t stream, std::string* err,
-                    const uint32_t* d_qmap = nullptr, const uint32_t* d_nq_live = nullptr);
+                    const uint32_t* d_qmap = nullptr, const uint32_t* d_nq_live = nullptr, const uint32_t* d_allow = nullptr);
 
 // ---- MFMA candidate pass (bf_mfma.hip) ----------------------------------------------------
 constexpr uint32_t kBfMfmaCap = 2048;     // candidate entries per query in the MFMA path

@@ -297,7 +297,24 @@ class BruteforceSearch:
         check(self._l.vdb_bf_to_device(self._h, device))
         return self
 
-    def search_batch(self, queries, k: int, precision: int = BF_FP32):
+    def labels(self) -> np.ndarray:
+        """Labels of the stored rows in storage order (vdb_bf_labels)."""
+        out = np.empty(self.getElementCount(), np.uint64)
+        check(self._l.vdb_bf_labels(self._h, out.ctypes.data_as(_u64p), out.size))
+        return out
+
+    def filter_bitmap(self, filter) -> np.ndarray:
+        """A BaseFilterFunctor's verdicts as the bitmap over rows the C-ABI takes: ``filter`` is a callable
+        label -> bool or a boolean array over the rows in storage order."""
+        n = self.getElementCount()
+        ok = np.fromiter((bool(filter(int(l))) for l in self.labels()), bool, n) if callable(filter) else np.asarray(filter, bool)
+        if ok.shape != (n,):
+            raise ValueError("boolean filter must have one entry per row")
+        return np.frombuffer(np.packbits(ok, bitorder="little").tobytes().ljust((n + 31) // 32 * 4, b"\0"), np.uint32)
+
+    def search_batch(self, queries, k: int, precision: int = BF_FP32, filter=None):
+        """``filter`` (callable, boolean array over rows, or on the device path an int32 CUDA bitmap): the
+        reference's filtered scan, always exact (vdb_bf_search_batch[_device]_filtered)."""
         if _is_torch_cuda(queries):
             import torch
 
@@ -306,6 +323,11 @@ class BruteforceSearch:
             dist = torch.empty((nq, k), dtype=torch.float32, device=q.device)
             label = torch.empty((nq, k), dtype=torch.int64, device=q.device)
             stream = torch.cuda.current_stream(q.device).cuda_stream
+            if filter is not None:
+                allow = filter if _is_torch_cuda(filter) else torch.from_numpy(self.filter_bitmap(filter).view(np.int32).copy()).to(q.device)
+                check(self._l.vdb_bf_search_batch_device_filtered(self._h, q.data_ptr(), nq, k, allow.data_ptr(), dist.data_ptr(),
+                                                                  label.data_ptr(), stream))
+                return dist, label
             check(self._l.vdb_bf_search_batch_device(self._h, q.data_ptr(), nq, k, precision, dist.data_ptr(),
                                                      label.data_ptr(), stream))
             return dist, label
@@ -313,14 +335,17 @@ class BruteforceSearch:
         nq = q.shape[0]
         dist = np.empty((nq, k), np.float32)
         label = np.empty((nq, k), np.uint64)
+        if filter is not None:
+            allow = self.filter_bitmap(filter)
+            check(self._l.vdb_bf_search_batch_filtered(self._h, q.ctypes.data_as(_f32p), nq, k, allow.ctypes.data_as(_u32p),
+                                                       dist.ctypes.data_as(_f32p), label.ctypes.data_as(_u64p)))
+            return dist, label
         check(self._l.vdb_bf_search_batch(self._h, q.ctypes.data_as(_f32p), nq, k, precision,
                                           dist.ctypes.data_as(_f32p), label.ctypes.data_as(_u64p)))
         return dist, label
 
     def SearchKNNCloserFirst(self, query, k: int, filter=None):
-        if filter is not None:
-            raise VdbError(_lib.VDB_ERR_UNSUPPORTED, "filtered search is not on the device path yet")
-        d, l = self.search_batch(np.asarray(query, np.float32).reshape(1, -1), k)
+        d, l = self.search_batch(np.asarray(query, np.float32).reshape(1, -1), k, filter=filter)
         keep = l[0] != np.uint64(0xFFFFFFFFFFFFFFFF)
         return [(float(a), int(b)) for a, b in zip(d[0][keep], l[0][keep])]
 
