@@ -222,6 +222,7 @@ struct GemmArgs {
     uint32_t* hit_q;         // [kGemmBlocks][hit_cap]
     uint32_t* hit_count;     // [kGemmBlocks]
     uint32_t hit_cap;
+    uint32_t dense;          // bf_gemm8_filter, first slab: every pair goes to entries[q][row - row_lo] (the host sets count[q])
 };
 
 // LDS image of one operand tile of one k-step: 256 rows x 64 B, no padding (LDS-DMA writes 1 KiB
@@ -600,6 +601,387 @@ __global__ __launch_bounds__(kGemmThreads) void bf_gemm_filter(GemmArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the over-issued steps before LDS is released
 }
 
+// ------------------------------------------------------------------ bf16 GEMM + filter, ping-pong schedule
+//
+// Same tile (256 base rows x 256 queries, 8 waves), same panels in HBM, same epilogue contract as
+// bf_gemm_filter<true>, another loop: the "256^2 8-phase" structure of the programming guide (§5), the fastest
+// plain-HIP bf16 GEMM measured on this chip.  What differs from the loop above:
+//
+//  * K advances 64 per K-tile (two 64-B panel steps).  A K-tile is four HALF-TILES of 16 KiB (128 rows x 2
+//    panels x 64 B): B rows 0-127, A rows 0-127, B rows 128-255, A rows 128-255, in that stream order; the
+//    ring holds two K-tiles = eight half-tiles (128 KiB).
+//  * A wave's 128 x 64 outputs are four QUADRANTS of 64 x 32, one per A half x B half: quadrant (i, j) =
+//    rows i*128 + wr*64 .. +63, queries j*128 + wc*32 .. +31.  So every wave needs the same half-tiles at the
+//    same time, and a K-tile is four PHASES: (0,0) (0,1) (1,1) (1,0), each 16 v_mfma_f32_16x16x32_bf16
+//    (4 row blocks x 2 query blocks x 2 k-blocks) on fragments read at the START of the phase: 12 reads
+//    (B half 0 first, then A half 0), 4 (B half 1), 8 (A half 1), none.
+//  * The two waves of a SIMD (wr = 0 / 1) run one barrier apart: while one issues its 16 MFMAs the other reads
+//    its fragments and issues its two DMA pieces - matrix pipe beside memory instructions, never both waves
+//    in the same kind of work.  Two barriers per phase.
+//  * Staging runs seven half-tiles ahead: phase P issues half-tile P + 7 of the stream.  One counted wait per
+//    K-tile (vmcnt(6) in its last phase: everything but the three youngest half-tiles has landed, i.e. the
+//    whole next K-tile), read from the phase after.  The slot half-tile h overwrites held h - 8, last read two
+//    phases earlier - except B half 0, read one phase earlier: its four reads are issued first in their phase
+//    and retired (lgkmcnt(8)) ahead of that phase's first barrier.
+constexpr int kHalfBytes = 16384;
+constexpr int kRing8Bytes = 8 * kHalfBytes;
+
+// what a lane of bf_gemm8_filter leaves for bf_scatter_recs: eight accumulators (approx dist - off[q]) of query q, of the
+// rows rbase + (i >> 2) * 16 + (i & 3).  One list per wave, in the memory of the other kernel's per-block lists.
+struct GemmRec {
+    float v[8];
+    uint32_t q, rbase;
+    uint32_t pad[2];
+};
+static_assert(sizeof(GemmRec) == 48, "three 16-byte stores");
+constexpr uint32_t kRecCap = kHitCap * 12u / (8u * sizeof(GemmRec));  // 512 records per wave and launch
+
+// 16-B chunk c of row r of a half-tile sits at chunk position c ^ swz4((r >> 2) & 3): a 16x16x32 fragment
+// read (lane l: row l & 15, chunk l >> 4) then puts the 16 lanes of each ds_read_b128 group on 16 distinct
+// 16-B slots of the 256-B bank row ({0, 2, 3, 1}: checked against the hardware's lane groups)
+__device__ __forceinline__ int swz4(int g) { return (0x78 >> (2 * g)) & 3; }
+
+// ABL (diagnostic builds only, VDB_GEMM_ABL, tools/exp_gemm.py): parts of the loop left out to see what they cost - 1 the
+// epilogue's screening, 2 the DMA, 4 the fragment reads, 8 the MFMAs.  Answers are wrong with any bit set.
+template <bool STAMPS, int ABL>
+__global__ __launch_bounds__(kGemmThreads) void bf_gemm8_filter(GemmArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kRing8Bytes + 4 * kAuxBytes];
+    unsigned char* aux_s = smem + kRing8Bytes;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    GemmRec* recs = reinterpret_cast<GemmRec*>(a.hit_key) + ((size_t)blockIdx.x * 8 + wave) * kRecCap;  // this wave's list
+    uint32_t rec_n = 0;
+    const uint32_t xcd = blockIdx.x & 7u, in = blockIdx.x >> 3;
+    const uint32_t sup_q = (a.tiles_q + 7u) >> 3, n_sup = sup_q * ((a.tiles_r + 3u) >> 2);
+    auto next_tile = [&](uint32_t s, uint32_t& tr, uint32_t& tq) __attribute__((always_inline)) {
+        for (; s < n_sup; s += 8u) {
+            tr = (s / sup_q) * 4u + (in >> 3);
+            tq = (s % sup_q) * 8u + (in & 7u);
+            if (tr < a.tiles_r && tq < a.tiles_q) break;
+        }
+        return s;
+    };
+    const uint32_t nk = a.ksteps >> 1;  // K-tiles per output tile (ksteps is even: K is padded to 64)
+
+    // ---- issue side.  A wave moves two pieces (16 rows x 64 B, 1 KiB, contiguous in the panels) of every
+    // half-tile: waves 0-3 the eight pieces of its first panel, waves 4-7 those of the second.
+    uint32_t tr_i = 0, tq_i = 0, s_iss = next_tile(xcd, tr_i, tq_i);
+    if (s_iss >= n_sup) {
+        if (lane == 0) a.hit_count[blockIdx.x * 8 + wave] = 0u;
+        return;
+    }
+    uint32_t kt_iss = 0, tile_iss = 0, hs = 0;
+    bool iss_live = true;
+    const char *a_src[2], *b_src[2];
+    const char* aux_src = nullptr;
+    auto set_src = [&]() __attribute__((always_inline)) {
+        const uint32_t row0 = a.row_lo + tr_i * kTile, q0 = tq_i * kTile;
+        const char* Ab = static_cast<const char*>(a.A) + (size_t)(row0 >> 8) * a.ksteps * kTileBytes;
+        const char* Bb = static_cast<const char*>(a.B) + (size_t)tq_i * a.ksteps * kTileBytes;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rin = ((2 * wave + i) & 7) * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ swz4((lane >> 4) & 3);
+            const size_t off = (size_t)(wave >> 2) * kTileBytes + rin * kRowB + c * 16;
+            a_src[i] = Ab + off;
+            b_src[i] = Bb + off;
+        }
+        aux_src = wave == 0   ? reinterpret_cast<const char*>(a.nx + row0)
+                  : wave == 1 ? reinterpret_cast<const char*>(a.tauhat + q0)
+                              : reinterpret_cast<const char*>(a.off + q0);
+        aux_src += lane * 16;
+    };
+    set_src();
+    // half-tile Q (stream position: 0 = B half 0, 1 = A half 0, 2 = B half 1, 3 = A half 1) of K-tile kt_iss
+    auto issue_half = [&](auto QC) __attribute__((always_inline)) {
+        constexpr int Q = decltype(QC)::value;
+        if (Q == 0 && iss_live && kt_iss == 0 && wave < 3) {
+            unsigned char* dst = aux_s + (tile_iss & 3u) * kAuxBytes + wave * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)aux_src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+        const size_t off = (size_t)kt_iss * (2 * kTileBytes) + (Q >> 1) * (128 * kRowB);
+        unsigned char* dst0 = smem + (hs & 7u) * kHalfBytes + (wave >> 2) * 8192;
+#pragma unroll
+        for (int i = 0; i < ((ABL & 2) ? 0 : 2); ++i) {
+            const char* src = ((Q & 1) ? a_src[i] : b_src[i]) + off;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst0 + ((2 * wave + i) & 7) * 1024), 16, 0, 0);
+        }
+        hs += 1;
+        if (Q == 3 && iss_live && ++kt_iss == nk) {
+            s_iss = next_tile(s_iss + 8u, tr_i, tq_i);
+            const bool more = s_iss < n_sup;  // past the last tile: keep re-reading its last K-tile (never computed)
+            if (more) set_src();
+            kt_iss = more ? 0u : nk - 1u;
+            tile_iss += more ? 1u : 0u;
+            iss_live = more;
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+
+    // ---- compute side
+    const uint32_t rb = (uint32_t)((lane & 15) * kRowB + (((lane >> 4) ^ swz4((lane >> 2) & 3)) * 16));
+    const uint32_t a_rd = rb + (uint32_t)(wr * 64 * kRowB), b_rd = rb + (uint32_t)(wc * 32 * kRowB);
+    // fragment of 16-row block `blk`, k-block s, of the half-tile in ring slot `slot`
+    auto rd = [&](uint32_t slot_off, uint32_t base, int blk, int s) __attribute__((always_inline)) {
+        if constexpr (ABL & 4) {
+            bf16x8 v;
+            asm volatile("" : "=v"(v));
+            return v;
+        } else {
+            return *reinterpret_cast<const bf16x8*>(smem + slot_off + base + s * 8192 + blk * 16 * kRowB);
+        }
+    };
+    f32x4 acc[8][4];  // [A half * 4 + row block][B half * 2 + query block]
+    bf16x8 af[4][2], b0[2][2], b1[2][2];
+    const bool is_l2 = a.metric == 0;
+
+    // P = phase of the K-tile whose ring half is `boff` (0 / 4 slots)
+    unsigned long long st[4][4] = {};  // STAMPS: [phase][load section, first barrier + read wait, MFMAs, second barrier]
+    auto phase = [&](auto PC, uint32_t boff) __attribute__((always_inline)) {
+        constexpr int P = decltype(PC)::value;
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if constexpr (STAMPS) t0 = stamp();
+        if constexpr (P == 0) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) b0[n][s] = rd(boff + 0 * kHalfBytes, b_rd, n, s);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) af[m][s] = rd(boff + 1 * kHalfBytes, a_rd, m, s);
+        } else if constexpr (P == 1) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) b1[n][s] = rd(boff + 2 * kHalfBytes, b_rd, n, s);
+        } else if constexpr (P == 2) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) af[m][s] = rd(boff + 3 * kHalfBytes, a_rd, m, s);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        issue_half(std::integral_constant<int, (P + 3) & 3>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (P == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // B half 0's reads: its slot is refilled next phase
+        if constexpr (P == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // the next K-tile has landed (read from the next phase on)
+        if constexpr (STAMPS) t1 = stamp();
+        __builtin_amdgcn_s_barrier();
+        if constexpr (P == 0)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[2][0]), "+v"(af[2][1]), "+v"(af[3][0]),
+                           "+v"(af[3][1]), "+v"(b0[0][0]), "+v"(b0[0][1]), "+v"(b0[1][0]), "+v"(b0[1][1]));
+        else if constexpr (P == 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1[0][0]), "+v"(b1[0][1]), "+v"(b1[1][0]), "+v"(b1[1][1]));
+        else if constexpr (P == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[2][0]), "+v"(af[2][1]), "+v"(af[3][0]),
+                           "+v"(af[3][1]));
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (STAMPS) t2 = stamp();
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int MI = (P >= 2) ? 4 : 0;              // A half 1 in phases 2, 3
+        constexpr int NJ = (P == 1 || P == 2) ? 2 : 0;    // B half 1 in phases 1, 2
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    if constexpr (ABL & 8) asm volatile("" : "+v"(acc[MI + m][NJ + n]) : "v"(af[m][s]), "v"(NJ ? b1[n][s] : b0[n][s]));
+                    else acc[MI + m][NJ + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][s], NJ ? b1[n][s] : b0[n][s], acc[MI + m][NJ + n], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (STAMPS) t3 = stamp();
+        __builtin_amdgcn_s_barrier();
+        if constexpr (STAMPS) {
+            const unsigned long long t4 = stamp();
+            st[P][0] += t1 - t0;
+            st[P][1] += t2 - t1;
+            st[P][2] += t3 - t2;
+            st[P][3] += t4 - t3;
+        }
+    };
+
+    // prologue: seven half-tiles in flight, K-tile 0 landed
+    issue_half(I0{});
+    issue_half(I1{});
+    issue_half(I2{});
+    issue_half(I3{});
+    issue_half(I0{});
+    issue_half(I1{});
+    issue_half(I2{});
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // the stagger: waves 4-7 run one barrier behind their SIMD partners
+
+    uint32_t g = 0, tile_cmp = 0, tr = 0, tq = 0;
+    unsigned long long t_begin = 0, rt_begin = 0, d_epi = 0;
+    if constexpr (STAMPS) {
+        t_begin = stamp();
+        rt_begin = __builtin_amdgcn_s_memrealtime();
+    }
+    for (uint32_t s_cmp = next_tile(xcd, tr, tq); s_cmp < n_sup; s_cmp = next_tile(s_cmp + 8u, tr, tq), ++tile_cmp) {
+        const unsigned char* aux = aux_s + (tile_cmp & 3u) * kAuxBytes;
+        if (is_l2) {
+            // the accumulators start at ||xc||^2 of their rows (this tile's norms came with its first half-tile)
+            const float* nx0 = reinterpret_cast<const float*>(aux) + wr * 64 + 4 * (lane >> 4);
+#pragma unroll
+            for (int M = 0; M < 8; ++M) {
+                const f32x4 nv = *reinterpret_cast<const f32x4*>(nx0 + (M >> 2) * 128 + (M & 3) * 16);
+#pragma unroll
+                for (int N = 0; N < 4; ++N) acc[M][N] = nv;
+            }
+        } else {
+#pragma unroll
+            for (int M = 0; M < 8; ++M)
+#pragma unroll
+                for (int N = 0; N < 4; ++N) acc[M][N] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (uint32_t kt = 0; kt < nk; ++kt, ++g) {
+            const uint32_t boff = (g & 1u) * (4u * kHalfBytes);
+            phase(I0{}, boff);
+            phase(I1{}, boff);
+            phase(I2{}, boff);
+            phase(I3{}, boff);
+        }
+
+        unsigned long long te0 = 0;
+        if constexpr (STAMPS) te0 = stamp();
+        // Epilogue.  A lane holds one query per query block (lane & 15) and 32 rows per query block.  approx dist =
+        // accumulator + off[q]; pairs at or below the query's running threshold are candidates.  Almost nothing
+        // passes (k' of a slab's rows per query), and deciding and appending INSIDE this loop is what used to cost:
+        // a dozen pairs per tile took 10 000 cycles (an LDS atomic and its wait per pair, the append written out
+        // once per accumulator register, every wave of the block waiting at the next barrier for the slowest).
+        // Now a lane whose 8 outputs of a group hold one at or below the (screening) threshold stores the eight
+        // raw accumulators as one RECORD in its wave's own list - slot from a counter in a register, three plain
+        // stores, nothing to wait for - and bf_scatter_recs decides pair by pair afterwards.
+        const uint32_t* th_s = reinterpret_cast<const uint32_t*>(aux + 1024);
+        const float* off_s = reinterpret_cast<const float*>(aux + 2048);
+        const uint32_t row0 = a.row_lo + tr * kTile, q0 = tq * kTile;
+        uint32_t passmask = 0;  // groups this wave handles in place (bit N * 4 + P: query block N, accumulators 2P and 2P+1)
+        if (a.dense) {
+            passmask = 0xFFFFu;
+        } else {
+#pragma unroll
+            for (int N = 0; N < 4; ++N) {
+                const int qi = (N >> 1) * 128 + wc * 32 + (N & 1) * 16 + (lane & 15);
+                const bool qok = q0 + qi < a.nq;
+                const uint32_t th = th_s[qi];
+                const bool open = th == 0xFFFFFFFFu;
+                const float tauf = ord2f(th), offq = off_s[qi];
+                // the threshold moved to the accumulator's side of the sum, with slack for the rounding of that move
+                float screen = (tauf - offq) + 1e-6f * (__builtin_fabsf(tauf) + __builtin_fabsf(offq));
+                screen = !qok ? -__builtin_inff() : open ? __builtin_inff() : screen;
+#pragma unroll
+                for (int P = 0; P < 4; ++P) {
+                    const f32x4 u = acc[2 * P][N], w = acc[2 * P + 1][N];
+                    float mn;  // (v_min3 by hand: fminf comes with a quieting v_max per operand; NaN is outside the contract)
+                    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(mn) : "v"(u[0]), "v"(u[1]), "v"(u[2]));
+                    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(mn) : "v"(mn), "v"(u[3]), "v"(w[0]));
+                    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(mn) : "v"(mn), "v"(w[1]), "v"(w[2]));
+                    asm("v_min_f32 %0, %1, %2" : "=v"(mn) : "v"(mn), "v"(w[3]));
+                    if constexpr (ABL & 1) {
+                        asm volatile("" ::"v"(mn));
+                        continue;
+                    }
+                    const bool hit = mn <= screen;
+                    const uint64_t pm = __builtin_amdgcn_ballot_w64(hit);
+                    if (pm == 0) continue;
+                    const uint32_t slot = rec_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                    rec_n += (uint32_t)__builtin_popcountll(pm);
+                    if (rec_n > kRecCap) {  // no room in the list: this group is handled in place, below
+                        rec_n -= (uint32_t)__builtin_popcountll(pm);
+                        passmask |= 1u << (N * 4 + P);
+                    } else if (hit) {
+                        GemmRec* r = recs + slot;
+                        *reinterpret_cast<f32x4*>(r->v) = u;
+                        *reinterpret_cast<f32x4*>(r->v + 4) = w;
+                        r->q = q0 + (uint32_t)qi;
+                        // accumulator M = 2P + (i >> 2), register i & 3: row M/4 * 128 + wr * 64 + M%4 * 16 + lane/16 * 4 + (i & 3)
+                        r->rbase = row0 + (uint32_t)((P >> 1) * 128 + wr * 64 + (P & 1) * 32 + (lane >> 4) * 4);
+                    }
+                }
+            }
+        }
+#pragma unroll 1
+        while (passmask) {  // the first slab (every pair is kept, at its row's place), and groups that found their list full
+            const int gi = __builtin_ctz(passmask);
+            passmask &= passmask - 1u;
+            f32x4 u, w;
+            switch (gi) {
+#define VDB_G8_CASE(G) case G: u = acc[2 * (G & 3)][G >> 2]; w = acc[2 * (G & 3) + 1][G >> 2]; break;
+                VDB_G8_CASE(0) VDB_G8_CASE(1) VDB_G8_CASE(2) VDB_G8_CASE(3) VDB_G8_CASE(4) VDB_G8_CASE(5) VDB_G8_CASE(6) VDB_G8_CASE(7)
+                VDB_G8_CASE(8) VDB_G8_CASE(9) VDB_G8_CASE(10) VDB_G8_CASE(11) VDB_G8_CASE(12) VDB_G8_CASE(13) VDB_G8_CASE(14)
+                default: u = acc[6][3]; w = acc[7][3]; break;
+#undef VDB_G8_CASE
+            }
+            const int N = gi >> 2, P = gi & 3;  // wave-uniform
+            const int qi = (N >> 1) * 128 + wc * 32 + (N & 1) * 16 + (lane & 15);
+            const uint32_t q = q0 + qi;
+            const bool qok = q < a.nq;
+            const uint32_t th = th_s[qi];
+            const bool open = th == 0xFFFFFFFFu;
+            const float tauf = ord2f(th), offq = off_s[qi];
+            const uint32_t rbase = row0 + (uint32_t)((P >> 1) * 128 + wr * 64 + (P & 1) * 32 + (lane >> 4) * 4);
+            const float v[8] = {u[0], u[1], u[2], u[3], w[0], w[1], w[2], w[3]};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t row = rbase + (uint32_t)((i >> 2) * 16 + (i & 3));
+                const float dh = v[i] + offq;
+                const bool live = qok && row < a.row_hi;
+                const uint64_t key = ((uint64_t)f2ord(dh) << 32) | row;
+                if (a.dense) {
+                    if (live) a.entries[(size_t)q * a.cap + (row - a.row_lo)] = key;
+                } else if (live && (open || dh <= tauf)) {
+                    const uint32_t pos = atomicAdd(&a.count[q], 1u);
+                    if (pos < a.cap) a.entries[(size_t)q * a.cap + pos] = key;
+                }
+            }
+        }
+        if constexpr (STAMPS) d_epi += stamp() - te0;
+    }
+    if constexpr (STAMPS) {
+        const unsigned long long t_end = stamp(), rt_end = __builtin_amdgcn_s_memrealtime();
+        if (a.row_lo == 229376u && (blockIdx.x == 0 || blockIdx.x == 77) && lane == 0 && (wave & 3) == 0) {
+            printf("[gemm8 stamps] block %u wave %d: tiles %u ktiles %u | total %llu cyc (%.3f GHz) | epilogue+init %llu\n", blockIdx.x, wave, tile_cmp, g,
+                   t_end - t_begin, (double)(t_end - t_begin) / (double)(rt_end - rt_begin) / 10.0, d_epi);
+            for (int p = 0; p < 4; ++p)
+                printf("[gemm8 stamps]   block %u wave %d phase %d per K-tile: load %llu  barrier1+readwait %llu  mfma %llu  barrier2 %llu\n", blockIdx.x, wave, p,
+                       st[p][0] / g, st[p][1] / g, st[p][2] / g, st[p][3] / g);
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // (the stagger's other end)
+    if (lane == 0) a.hit_count[blockIdx.x * 8 + wave] = rec_n;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the over-issued half-tiles before LDS is released
+}
+
+// the records of every wave -> the queries' candidate buffers: eight threads per record, one pair each, decided here
+// with the threshold the GEMM screened against (tau_hat changes only between slabs)
+__global__ __launch_bounds__(256) void bf_scatter_recs(const GemmRec* recs, const uint32_t* rec_count, const float* off, const uint32_t* tauhat,
+                                                       uint32_t row_hi, uint32_t nq, uint32_t* count, uint64_t* entries, uint32_t cap) {
+    const uint32_t n = rec_count[blockIdx.x];
+    const GemmRec* list = recs + (size_t)blockIdx.x * kRecCap;
+    for (uint32_t t = threadIdx.x; t < n * 8u; t += 256u) {
+        const GemmRec& r = list[t >> 3];
+        const uint32_t i = t & 7u, q = r.q, row = r.rbase + (i >> 2) * 16u + (i & 3u);
+        if (q >= nq || row >= row_hi) continue;
+        const uint32_t th = tauhat[q];
+        const float dh = r.v[i] + off[q];
+        if (th == 0xFFFFFFFFu || dh <= ord2f(th)) {
+            const uint32_t pos = atomicAdd(&count[q], 1u);
+            if (pos < cap) entries[(size_t)q * cap + pos] = ((uint64_t)f2ord(dh) << 32) | row;
+        }
+    }
+}
+
 // the listed pairs of every block -> the queries' candidate buffers (the returning atomics live here)
 __global__ __launch_bounds__(256) void bf_scatter_hits(const uint64_t* hit_key, const uint32_t* hit_q, const uint32_t* hit_count,
                                                        uint32_t hit_cap, uint32_t* count, uint64_t* entries, uint32_t cap) {
@@ -676,14 +1058,39 @@ __global__ __launch_bounds__(64) void bf_rerank(RerankArgs a) {
     }
 }
 
+// the bf16 pass runs the ping-pong kernel unless the A/B switch asks for the loop before it (K is padded to 64, so ksteps is even)
+bool gemm8_selected(bool bf16, uint32_t ksteps) {
+    static const bool one_barrier = std::getenv("VDB_GEMM_ONE_BARRIER") != nullptr;
+    return bf16 && !one_barrier && (ksteps & 1u) == 0u;
+}
+
 void launch_gemm(bool bf16, dim3 grid, hipStream_t stream, const GemmArgs& g) {
     static const bool stamps = std::getenv("VDB_GEMM_STAMPS") != nullptr;  // diagnostics (bf16 only), tools/exp_gemm.py
     auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), 0, stream, g); };
     if (!bf16) go(bf_gemm_filter<false, false>);
-    else if (stamps) go(bf_gemm_filter<true, true>);
-    else go(bf_gemm_filter<true, false>);
-    hipLaunchKernelGGL(bf_scatter_hits, dim3(kGemmBlocks * 4), dim3(256), 0, stream, g.hit_key, g.hit_q, g.hit_count, g.hit_cap,
-                       g.count, g.entries, g.cap);
+    else if (!gemm8_selected(bf16, g.ksteps)) {
+        if (stamps) go(bf_gemm_filter<true, true>);
+        else go(bf_gemm_filter<true, false>);
+    } else if (stamps) go(bf_gemm8_filter<true, 0>);
+    else {
+        static const int abl = std::getenv("VDB_GEMM_ABL") ? std::atoi(std::getenv("VDB_GEMM_ABL")) : 0;
+        switch (abl) {
+            case 1: go(bf_gemm8_filter<false, 1>); break;
+            case 2: go(bf_gemm8_filter<false, 2>); break;
+            case 3: go(bf_gemm8_filter<false, 3>); break;
+            case 4: go(bf_gemm8_filter<false, 4>); break;
+            case 7: go(bf_gemm8_filter<false, 7>); break;
+            case 8: go(bf_gemm8_filter<false, 8>); break;
+            case 9: go(bf_gemm8_filter<false, 9>); break;
+            default: go(bf_gemm8_filter<false, 0>); break;
+        }
+    }
+    if (gemm8_selected(bf16, g.ksteps))
+        hipLaunchKernelGGL(bf_scatter_recs, dim3(kGemmBlocks * 8), dim3(256), 0, stream, reinterpret_cast<const GemmRec*>(g.hit_key), g.hit_count,
+                           g.off, g.tauhat, g.row_hi, g.nq, g.count, g.entries, g.cap);
+    else
+        hipLaunchKernelGGL(bf_scatter_hits, dim3(kGemmBlocks * 4), dim3(256), 0, stream, g.hit_key, g.hit_q, g.hit_count, g.hit_cap,
+                           g.count, g.entries, g.cap);
 }
 
 template <typename T>
@@ -740,7 +1147,7 @@ size_t bf_mfma_workspace_bytes(uint32_t nq, uint32_t vstride, uint32_t kp64) {
     add(((size_t)nq + 1) * 4);            // redo
     add((size_t)kGemmBlocks * kHitCap * 8);  // hit_key
     add((size_t)kGemmBlocks * kHitCap * 4);  // hit_q
-    add((size_t)kGemmBlocks * 4);            // hit_count
+    add((size_t)kGemmBlocks * 8 * 4);        // hit_count (per block, or per wave: bf_gemm8_filter)
     return b + 4096 + bf_exact_workspace_bytes(nq);
 }
 
@@ -766,7 +1173,7 @@ int launch_bf_mfma(const BfDeviceData& d, int precision, const float* d_queries,
     uint32_t* redo = carve<uint32_t>(p, (size_t)nq + 1);
     uint64_t* hit_key = carve<uint64_t>(p, (size_t)kGemmBlocks * kHitCap);
     uint32_t* hit_q = carve<uint32_t>(p, (size_t)kGemmBlocks * kHitCap);
-    uint32_t* hit_count = carve<uint32_t>(p, kGemmBlocks);
+    uint32_t* hit_count = carve<uint32_t>(p, kGemmBlocks * 8);
     void* exact_ws = p;
 
     hipError_t e = hipMemsetAsync(count, 0, (size_t)nq * 4, stream);
@@ -822,6 +1229,11 @@ int launch_bf_mfma(const BfDeviceData& d, int precision, const float* d_queries,
         g.tiles_r = (hi - lo + kTile - 1) / kTile;
         g.tiles_q = (nq + kTile - 1) / kTile;
         const dim3 grid(kGemmBlocks);  // persistent: the blocks walk the tiles (see the kernel)
+        // first slab of the ping-pong kernel: no query has a threshold yet and every pair is kept - written straight
+        // to its row's place in the query's buffer instead of going through the lists (slab <= cap - k' rows)
+        g.dense = (lo == 0 && gemm8_selected(bf16, g.ksteps)) ? 1u : 0u;
+        if (g.dense) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(count), (int)(hi - lo), nq, stream);
+        if (e != hipSuccess) break;
         launch_gemm(bf16, grid, stream, g);
         e = hipGetLastError();
         if (e == hipSuccess) e = enqueue_bf_compact(c, stream);
