@@ -495,9 +495,9 @@ def run_bruteforce(args, dev, cores, threads, standalone: bool):
         peak = MFMA_PEAK_TF["fp32" if name == "fp32" else "bf16"]
         return {"ms_per_batch": round(ms, 3), "queries_per_s": round(nq / ms * 1e3, 1),
                 "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                             "traffic": None, "kernel": f"bf_gemm_filter<{'f32' if name == 'fp32' else 'bf16'}>",
+                             "traffic": None, "kernel": "bf_gemm_filter (f32)" if name == "fp32" else "bf_gemm8_filter (bf16)",
                              "kernel_ms": round(ms, 3),
-                             "kernel_ms_note": "HIP events around the whole step on its stream: prepare-queries, 14 slab launches of "
+                             "kernel_ms_note": "HIP events around the whole step on its stream: prepare-queries, the slab launches of "
                                                "GEMM+filter, compactions, exact re-rank (the GEMM's own time: profiles/)",
                              "algorithmic_flops_per_launch": flops}}
 

@@ -1,6 +1,7 @@
 """Per-dispatch durations of the last brute-force step in a rocprofv3 --kernel-trace CSV (tools/trace_c3.sh)."""
 import csv, glob, sys
-f = sorted(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'))[-1]
+import os
+f = max(glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"), key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'bf_prep_queries' in r['Kernel_Name']]
 start = idx[-1]
