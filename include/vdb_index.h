@@ -176,6 +176,24 @@ int vdb_search_batch_device_filtered(const vdb_index* idx, const float* d_querie
                                      uint32_t* d_out_stats, void* stream);
 int vdb_search_batch_filtered(const vdb_index* idx, const float* queries, size_t nq, size_t k, const uint32_t* allow,
                               float* out_dist, uint64_t* out_label, uint32_t* out_stats);
+/* searchStopConditionClosest(query, stop_condition, filter): hnsw_core.hpp:1162-1213 - the greedy descent of
+ * searchKnn, then the non-bare layer-0 search driven by a BaseSearchStopCondition (hnswlib.hpp:10-23) instead of
+ * ef, results closest first, the condition's filter_results last.  Six host callbacks per candidate cannot run in a
+ * kernel, and the reference defines no concrete condition, so ONE crosses the ABI as plain numbers: the epsilon-radius
+ * condition of the library the reference's index derives from (hnswlib 0.8.0, EpsilonSearchStopCondition) - stop once
+ * the best open candidate lies beyond `epsilon` and min_num_candidates results are held; keep at most
+ * max_num_candidates (<= 508) results; return those within epsilon.  Parity of this entry point is unpinned
+ * (oracle/vdb_oracle.hpp says why).
+ *   d_out_dist / d_out_label  [nq * max_num_candidates], ascending (dist, label), padded with +inf / UINT64_MAX
+ *   d_out_stats  nullable [nq * 4] as above; stats[4 q + 3] = number of results of query q
+ *   d_allow      as vdb_search_batch_device_filtered; NULL = every element (deleted ones are always excluded)
+ * DEVIATION: :1205 hands back INTERNAL ids; this returns labels like every other search. */
+int vdb_search_epsilon_batch_device(const vdb_index* idx, const float* d_queries, size_t nq, float epsilon,
+                                    size_t min_num_candidates, size_t max_num_candidates, const uint32_t* d_allow,
+                                    float* d_out_dist, uint64_t* d_out_label, uint32_t* d_out_stats, void* stream);
+int vdb_search_epsilon_batch(const vdb_index* idx, const float* queries, size_t nq, float epsilon, size_t min_num_candidates,
+                             size_t max_num_candidates, const uint32_t* allow, float* out_dist, uint64_t* out_label,
+                             uint32_t* out_stats);
 /* getExternalLabel (hnsw_core.hpp:219-221) for internal ids 0 .. count-1; cap >= count. */
 int vdb_index_labels(const vdb_index* idx, uint64_t* out, size_t cap);
 

@@ -65,6 +65,8 @@ def _sig(lib):
     lib.orc_hnsw_search.restype = C.c_double
     lib.orc_hnsw_search.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, f32p, szp, u32p, u64p, u64p, u64p,
                                     C.c_int, C.c_size_t, C.c_size_t]
+    lib.orc_hnsw_search_epsilon.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_float, C.c_size_t, C.c_size_t, f32p, szp, u32p,
+                                            u64p, u64p, C.c_size_t, C.c_size_t]
     lib.orc_bf_create.restype = C.c_void_p
     lib.orc_bf_create.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t]
     lib.orc_bf_load.restype = C.c_void_p
@@ -219,6 +221,23 @@ class OracleHNSW:
         if secs < 0:
             raise RuntimeError(_err(self._l))
         return dict(dist=dist, label=label, count=count, ndis=ndis, nhops0=nh0, nhops_upper=nhu, seconds=secs)
+
+    def search_epsilon(self, queries, epsilon: float, min_cand: int, max_cand: int, filter_mod: int = 0, filter_keep: int = 0):
+        """searchStopConditionClosest with the epsilon condition -> dict(dist [nq,max_cand], label, count, ndis, nhops0)"""
+        queries, pq = _f32(queries)
+        nq = queries.shape[0]
+        dist = np.empty((nq, max_cand), np.float32)
+        label = np.empty((nq, max_cand), np.uint64)
+        count = np.empty(nq, np.uint32)
+        ndis, nh0 = (np.empty(nq, np.uint64) for _ in range(2))
+        u64p = C.POINTER(C.c_uint64)
+        rc = self._l.orc_hnsw_search_epsilon(
+            self._h, pq, nq, epsilon, min_cand, max_cand, dist.ctypes.data_as(C.POINTER(C.c_float)),
+            label.ctypes.data_as(C.POINTER(C.c_size_t)), count.ctypes.data_as(C.POINTER(C.c_uint)), ndis.ctypes.data_as(u64p),
+            nh0.ctypes.data_as(u64p), filter_mod, filter_keep)
+        if rc != 0:
+            raise RuntimeError(_err(self._l))
+        return dict(dist=dist, label=label, count=count, ndis=ndis, nhops0=nh0)
 
 
 class OracleBruteforce:

@@ -1,6 +1,7 @@
 // oracle_capi.cpp — plain-C entry points over vdb_oracle.hpp so that tests/ and
 // bench.py's cpu_baseline leg can drive the CPU restatement through ctypes.
 // TEST INFRASTRUCTURE ONLY (see the header of vdb_oracle.hpp).
+#include <algorithm>
 #include <chrono>
 #include <thread>
 
@@ -188,6 +189,37 @@ double orc_hnsw_search(void* h, const float* queries, size_t nq, size_t k, float
         return -1.0;
     }
     return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// searchStopConditionClosest (hnsw_core.hpp:1162-1213) with the epsilon condition for nq queries.  Outputs are
+// [nq * max_cand], closest first (ties by label, as the GPU epilogue orders them), padded with (+inf, SIZE_MAX);
+// out_count[q] = results of query q.  Returns 0, < 0 on error.
+int orc_hnsw_search_epsilon(void* h, const float* queries, size_t nq, float epsilon, size_t min_cand, size_t max_cand,
+                            float* out_dist, size_t* out_label, unsigned* out_count, uint64_t* out_ndis, uint64_t* out_nhops0,
+                            size_t filter_mod, size_t filter_keep) {
+    auto* idx = static_cast<HierarchicalNSW*>(h);
+    const size_t dim = idx->space_.dim;
+    ModFilter mf;
+    mf.mod = filter_mod;
+    mf.keep = filter_keep;
+    try {
+        for (size_t q = 0; q < nq; q++) {
+            EpsilonSearchStopCondition stop(epsilon, min_cand, max_cand);
+            SearchStats st;
+            auto res = idx->searchStopConditionClosest(queries + q * dim, stop, filter_mod ? &mf : nullptr, &st);
+            std::stable_sort(res.begin(), res.end());  // (dist, label): the tie order of DESIGN.md
+            for (size_t i = 0; i < max_cand; i++) {
+                out_dist[q * max_cand + i] = i < res.size() ? res[i].first : std::numeric_limits<float>::infinity();
+                out_label[q * max_cand + i] = i < res.size() ? res[i].second : (size_t)-1;
+            }
+            if (out_count) out_count[q] = (unsigned)res.size();
+            if (out_ndis) out_ndis[q] = st.ndis;
+            if (out_nhops0) out_nhops0[q] = st.nhops0;
+        }
+    } catch (const std::exception& e) {
+        return fail(e);
+    }
+    return 0;
 }
 
 // ---- brute force -------------------------------------------------------------

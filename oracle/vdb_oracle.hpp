@@ -205,6 +205,52 @@ public:
     virtual ~BaseFilterFunctor() {}
 };
 
+// hnswlib.hpp:10-23: the protocol searchStopConditionClosest (hnsw_core.hpp:1162-1213) drives its layer-0 search with.
+// The reference holds this abstract class only - no concrete condition, and the function that would call it
+// (searchBaseLayerST) is undefined - so where and how the six callbacks are invoked is restated from the library the
+// reference's index derives from (hnswlib 0.8.0, hnswalg.h searchBaseLayerST): PARITY UNPINNED for everything that
+// involves a stop condition.
+class BaseSearchStopCondition {
+public:
+    virtual void add_point_to_result(label_t label, const void* datapoint, float dist) = 0;
+    virtual void remove_point_from_result(label_t label, const void* datapoint, float dist) = 0;
+    virtual bool should_stop_search(float candidate_dist, float lowerBound) const = 0;
+    virtual bool should_consider_candidate(float candidate_dist, float lowerBound) const = 0;
+    virtual bool should_remove_extra() const = 0;
+    virtual void filter_results(std::vector<std::pair<float, label_t>>& candidates) = 0;
+    virtual ~BaseSearchStopCondition() = default;
+};
+
+// The one concrete condition carried across the C-ABI (a closed set: callbacks cannot run inside a kernel): the
+// epsilon-radius condition of hnswlib 0.8.0 stop_condition.h (EpsilonSearchStopCondition), restated; the reference
+// defines none.  Results within `epsilon` of the query, at least min_num_candidates examined, at most max_num_candidates kept.
+class EpsilonSearchStopCondition : public BaseSearchStopCondition {
+public:
+    float epsilon_;
+    size_t min_num_candidates_, max_num_candidates_, curr_num_items_ = 0;
+    EpsilonSearchStopCondition(float epsilon, size_t min_num_candidates, size_t max_num_candidates)
+        : epsilon_(epsilon), min_num_candidates_(min_num_candidates), max_num_candidates_(max_num_candidates) {
+        if (min_num_candidates > max_num_candidates) throw std::runtime_error("min_num_candidates > max_num_candidates");
+    }
+    void add_point_to_result(label_t, const void*, float) override { curr_num_items_ += 1; }
+    void remove_point_from_result(label_t, const void*, float) override { curr_num_items_ -= 1; }
+    bool should_stop_search(float candidate_dist, float lowerBound) const override {
+        // the new candidate cannot improve the results held
+        if (candidate_dist > lowerBound && curr_num_items_ == max_num_candidates_) return true;
+        // the new candidate is outside the epsilon region and the minimum number of candidates has been seen
+        if (candidate_dist > epsilon_ && curr_num_items_ >= min_num_candidates_) return true;
+        return false;
+    }
+    bool should_consider_candidate(float candidate_dist, float lowerBound) const override {
+        return curr_num_items_ < max_num_candidates_ || lowerBound > candidate_dist;
+    }
+    bool should_remove_extra() const override { return curr_num_items_ > max_num_candidates_; }
+    void filter_results(std::vector<std::pair<float, label_t>>& candidates) override {
+        while (!candidates.empty() && candidates.back().first > epsilon_) candidates.pop_back();
+        while (candidates.size() > max_num_candidates_) candidates.pop_back();
+    }
+};
+
 // hnswlib.hpp:71-99
 class AlgorithmInterface {
 public:
@@ -463,9 +509,11 @@ public:
     //  admit test `size < ef || lowerBound > d` (:339); candidates always pushed, results
     //  only when bare or (not deleted and filter(label)) (:340-343); trim to ef (:345-346);
     //  lowerBound = top().first when non-empty (:348-349); seeding as :302-312.
+    // With a stop condition (the call at :1201; never together with `bare`) its callbacks replace the three tests and
+    // see every result come and go - placement as in hnswlib 0.8.0 (see BaseSearchStopCondition above).
     template <bool bare>
     ResultHeap searchBaseLayerST(idx_t ep, const void* q, size_t ef, BaseFilterFunctor* filter,
-                                 SearchStats* st) const {
+                                 SearchStats* st, BaseSearchStopCondition* stop = nullptr) const {
         VisitedList* vl = visited_pool_->getFreeVisitedList();
         tag_t* seen = vl->visitedAt;
         tag_t tag = vl->currentVisited;
@@ -477,6 +525,7 @@ public:
             float d = space_(q, getDataByInternalId(ep));  // same value searchKnn already counted
             lower_bound = d;
             top.emplace(d, ep);
+            if (!bare && stop) stop->add_point_to_result(getExternalLabel(ep), getDataByInternalId(ep), d);
             cand.emplace(-d, ep);
         } else {
             lower_bound = std::numeric_limits<float>::max();
@@ -489,6 +538,8 @@ public:
             float cd = -cur.first;
             if (bare) {
                 if (cd > lower_bound) break;
+            } else if (stop) {
+                if (stop->should_stop_search(cd, lower_bound)) break;
             } else {
                 if (cd > lower_bound && top.size() == ef) break;
             }
@@ -503,11 +554,23 @@ public:
                 seen[nb] = tag;
                 float d = space_(q, getDataByInternalId(nb));
                 if (st) st->ndis++;
-                if (top.size() < ef || lower_bound > d) {
+                const bool consider = (!bare && stop) ? stop->should_consider_candidate(d, lower_bound)
+                                                      : (top.size() < ef || lower_bound > d);
+                if (consider) {
                     cand.emplace(-d, nb);
-                    if (bare || (!isMarkedDeleted(nb) && (!filter || (*filter)(getExternalLabel(nb)))))
+                    if (bare || (!isMarkedDeleted(nb) && (!filter || (*filter)(getExternalLabel(nb))))) {
                         top.emplace(d, nb);
-                    if (top.size() > ef) top.pop();
+                        if (!bare && stop) stop->add_point_to_result(getExternalLabel(nb), getDataByInternalId(nb), d);
+                    }
+                    if (!bare && stop) {
+                        while (stop->should_remove_extra()) {
+                            const idx_t id = top.top().second;
+                            top.pop();
+                            stop->remove_point_from_result(getExternalLabel(id), getDataByInternalId(id), d);
+                        }
+                    } else if (top.size() > ef) {
+                        top.pop();
+                    }
                     if (!top.empty()) lower_bound = top.top().first;
                 }
             }
@@ -767,6 +830,52 @@ public:
             result.push(std::pair<float, label_t>(t.first, getExternalLabel(t.second)));
             top.pop();
         }
+        return result;
+    }
+
+    // hnsw_core.hpp:1162-1213.  Greedy descent as searchKnn, then the NON-bare layer-0 search with ef = 0 and the
+    // condition (:1201), results closest first, the condition's filter_results last (:1210).
+    // DEVIATION: :1205 copies the heap's (distance, INTERNAL id) pairs into the result; every other search of the
+    // interface returns external labels (:1155), and so does this restatement.
+    std::vector<std::pair<float, label_t>> searchStopConditionClosest(const void* query, BaseSearchStopCondition& stop_condition,
+                                                                      BaseFilterFunctor* filter = nullptr,
+                                                                      SearchStats* st = nullptr) const {
+        std::vector<std::pair<float, label_t>> result;
+        if (element_count_ == 0) return result;
+        idx_t cur_obj = entry_id_;
+        float cur_d = space_(query, getDataByInternalId(entry_id_));
+        if (st) st->ndis++;
+        for (int level = max_level_; level > 0; level--) {
+            bool changed = true;
+            while (changed) {
+                changed = false;
+                idx_t* list = get_neighbors(cur_obj, level);
+                int n = getListCount(list);
+                if (st) {
+                    st->nhops_upper++;
+                    st->ndis += n;
+                }
+                idx_t* ids = list + 1;
+                for (int i = 0; i < n; i++) {
+                    idx_t cand = ids[i];
+                    if (cand > capacity_) throw std::runtime_error("cand error");
+                    float d = space_(query, getDataByInternalId(cand));
+                    if (d < cur_d) {
+                        cur_d = d;
+                        cur_obj = cand;
+                        changed = true;
+                    }
+                }
+            }
+        }
+        ResultHeap top = searchBaseLayerST<false>(cur_obj, query, 0, filter, st, &stop_condition);
+        size_t size = top.size();
+        result.resize(size);
+        while (!top.empty()) {
+            result[--size] = std::pair<float, label_t>(top.top().first, getExternalLabel(top.top().second));
+            top.pop();
+        }
+        stop_condition.filter_results(result);
         return result;
     }
 

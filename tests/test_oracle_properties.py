@@ -2,6 +2,8 @@
 import numpy as np
 import pytest
 
+from vectordb_amd import datasets
+
 
 def test_bruteforce_equals_argsort(orc):
     rng = np.random.default_rng(3)
@@ -71,3 +73,28 @@ def test_filter_and_delete_paths(orc):
         o.mark_delete(0)
     r = o.search(x[:20], 5, filter_mod=2, filter_keep=1)
     assert np.all(r["label"] % 2 == 1) and np.all(r["label"] % 3 != 0)
+
+
+def test_epsilon_stop_condition_properties(orc):
+    """searchStopConditionClosest with the epsilon condition (restated from hnswlib 0.8.0: parity unpinned, see
+    oracle/vdb_oracle.hpp): with epsilon = +inf it is the non-bare search at ef = max_num_candidates; with a finite
+    epsilon the results are a prefix of that order cut at epsilon, never more than max, and the search does less work."""
+    x = datasets.clustered(4000, 24, 5)
+    q = datasets.clustered(60, 24, 6)
+    o = orc.OracleHNSW(orc.L2, 24, 4000, M=12, ef_construction=100, mode=orc.TREE64)
+    o.add(x)
+    mx = 40
+    o.set_ef(mx)
+    full = o.search(q, mx, filter_mod=1, filter_keep=0)          # a filter that accepts everything: the non-bare path
+    e = o.search_epsilon(q, float("inf"), 3, mx)
+    np.testing.assert_array_equal(e["label"], full["label"])
+    np.testing.assert_array_equal(e["dist"].view(np.uint32), full["dist"].view(np.uint32))
+    np.testing.assert_array_equal(e["ndis"], full["ndis"])
+    eps = float(np.median(full["dist"][:, 8]))
+    e = o.search_epsilon(q, eps, mx, mx)                         # min = max: stops early only once max results are held
+    assert (e["ndis"] <= full["ndis"]).all()
+    for i in range(len(q)):
+        c = int(e["count"][i])
+        assert c <= mx and (e["dist"][i, :c] <= eps).all() and np.isinf(e["dist"][i, c:]).all()
+    with pytest.raises(RuntimeError):
+        o.search_epsilon(q, 1.0, 5, 4)

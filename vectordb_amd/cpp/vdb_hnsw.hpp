@@ -32,6 +32,43 @@ public:
     virtual ~BaseFilterFunctor() {}
 };
 
+// hnswlib.hpp:10-23.  The device search cannot call back into the host per candidate, so the conditions it runs are a
+// closed set known to the library; the one there is: EpsilonSearchStopCondition (the reference defines none; this
+// is hnswlib 0.8.0's).  Any other subclass is refused by searchStopConditionClosest.
+template <typename dist_t>
+class BaseSearchStopCondition {
+public:
+    virtual void add_point_to_result(labeltype label, const void* datapoint, dist_t dist) = 0;
+    virtual void remove_point_from_result(labeltype label, const void* datapoint, dist_t dist) = 0;
+    virtual bool should_stop_search(dist_t candidate_dist, dist_t lowerBound) const = 0;
+    virtual bool should_consider_candidate(dist_t candidate_dist, dist_t lowerBound) const = 0;
+    virtual bool should_remove_extra() const = 0;
+    virtual void filter_results(std::vector<std::pair<dist_t, labeltype>>& candidates) = 0;
+    virtual ~BaseSearchStopCondition() = default;
+};
+
+class EpsilonSearchStopCondition : public BaseSearchStopCondition<float> {
+public:
+    float epsilon_;
+    size_t min_num_candidates_, max_num_candidates_, curr_num_items_ = 0;
+    EpsilonSearchStopCondition(float epsilon, size_t min_num_candidates, size_t max_num_candidates)
+        : epsilon_(epsilon), min_num_candidates_(min_num_candidates), max_num_candidates_(max_num_candidates) {}
+    void add_point_to_result(labeltype, const void*, float) override { curr_num_items_ += 1; }
+    void remove_point_from_result(labeltype, const void*, float) override { curr_num_items_ -= 1; }
+    bool should_stop_search(float candidate_dist, float lowerBound) const override {
+        if (candidate_dist > lowerBound && curr_num_items_ == max_num_candidates_) return true;
+        return candidate_dist > epsilon_ && curr_num_items_ >= min_num_candidates_;
+    }
+    bool should_consider_candidate(float candidate_dist, float lowerBound) const override {
+        return curr_num_items_ < max_num_candidates_ || lowerBound > candidate_dist;
+    }
+    bool should_remove_extra() const override { return curr_num_items_ > max_num_candidates_; }
+    void filter_results(std::vector<std::pair<float, labeltype>>& candidates) override {
+        while (!candidates.empty() && candidates.back().first > epsilon_) candidates.pop_back();
+        while (candidates.size() > max_num_candidates_) candidates.pop_back();
+    }
+};
+
 template <typename dist_t>
 class AlgorithmInterface {  // hnswlib.hpp:71-99
 public:
@@ -162,6 +199,26 @@ public:
     std::priority_queue<std::pair<float, labeltype>> SearchKNN(const void* query, size_t k,
                                                                BaseFilterFunctor* filter = nullptr) const override {
         return searchKnn(query, k, filter);
+    }
+    // hnsw_core.hpp:1162-1213: (distance, label) closest first, at most the condition's max_num_candidates of them.
+    // (the reference's :1205 hands back internal ids; labels here, as from searchKnn)
+    std::vector<std::pair<float, labeltype>> searchStopConditionClosest(const void* query_data,
+                                                                        BaseSearchStopCondition<float>& stop_condition,
+                                                                        BaseFilterFunctor* isIdAllowed = nullptr) const {
+        auto* eps = dynamic_cast<EpsilonSearchStopCondition*>(&stop_condition);
+        if (!eps) throw std::runtime_error("searchStopConditionClosest: the device path runs EpsilonSearchStopCondition only");
+        sync_device();
+        const size_t k = eps->max_num_candidates_;
+        std::vector<float> d(k);
+        std::vector<uint64_t> l(k);
+        std::vector<uint32_t> allow;
+        if (isIdAllowed) allow = filterBitmap(*isIdAllowed);
+        vdb_check(vdb_search_epsilon_batch(idx_, static_cast<const float*>(query_data), 1, eps->epsilon_, eps->min_num_candidates_, k,
+                                           isIdAllowed ? allow.data() : nullptr, d.data(), l.data(), nullptr));
+        std::vector<std::pair<float, labeltype>> result;
+        for (size_t i = 0; i < k; ++i)
+            if (l[i] != std::numeric_limits<uint64_t>::max()) result.emplace_back(d[i], (labeltype)l[i]);
+        return result;
     }
     vdb_index* handle() const { return idx_; }
 

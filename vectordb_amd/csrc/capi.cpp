@@ -450,16 +450,30 @@ void require_search_ready(const vdb_index* idx) {
         throw DeviceError("index changed since vdb_index_to_device: upload it again");
 }
 
+// The epsilon stop condition of searchStopConditionClosest (hnsw_core.hpp:1162-1213; the one condition that crosses the ABI).
+struct EpsilonStop {
+    float epsilon;
+    size_t min_num_candidates, max_num_candidates;
+};
+
 // searchKnn over a batch; d_filter = nullable device bitmap over internal ids (1 = passes the filter).
+// stop != nullptr: searchStopConditionClosest instead - the non-bare layer-0 search with ef = k = max_num_candidates.
 int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, const uint32_t* d_filter, float* d_out_dist,
-                  uint64_t* d_out_label, uint32_t* d_out_stats, hipStream_t stream, uint32_t** fail_word) {
+                  uint64_t* d_out_label, uint32_t* d_out_stats, hipStream_t stream, uint32_t** fail_word,
+                  const EpsilonStop* stop = nullptr) {
     require_search_ready(idx);
+    if (stop) {
+        if (!(stop->epsilon == stop->epsilon)) throw std::invalid_argument("epsilon is NaN");
+        if (stop->max_num_candidates == 0 || stop->min_num_candidates > stop->max_num_candidates)
+            throw std::invalid_argument("stop condition: need 0 < max_num_candidates and min_num_candidates <= max_num_candidates");
+        if (k != stop->max_num_candidates) throw std::invalid_argument("stop condition: the output rows hold max_num_candidates entries");
+    }
     if (nq == 0) return (int)VDB_OK;
     if (!d_queries || !d_out_dist || !d_out_label) throw std::invalid_argument("null buffer");
     if (k == 0) throw std::invalid_argument("k must be > 0");
     if (nq > 0x7FFFFFFFull || k > 0x7FFFFFFFull) throw std::invalid_argument("batch too large");
     DeviceGuard guard(idx->device);
-    const size_t ef = std::max(idx->host->ef_search, k);  // hnsw_core.hpp:1144
+    const size_t ef = stop ? k : std::max(idx->host->ef_search, k);  // hnsw_core.hpp:1144; :1201 passes no ef, the condition bounds the set
     if (ef > kMaxEf) throw Unsupported("max(efSearch, k) above 508 is not supported by the device path");
     std::unique_lock<std::mutex> lock(idx->scratch_lock);
     SearchScratch& s = scratch_for(idx, stream, nq);
@@ -477,6 +491,14 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
                 throw DeviceError("bitmap kernel launch failed");
             allow = (const uint32_t*)s.allow.p;
         }
+    }
+    if (stop && !allow) {  // a stop condition always runs the non-bare search (:1201): every node allowed
+        if (s.allow.bytes < (size_t)std::max(words, 1u) * 4) {
+            if (s.allow.p) VDB_HIP(hipStreamSynchronize(stream));
+            s.allow.alloc((size_t)std::max(words, 1u) * 4);
+        }
+        VDB_HIP(hipMemsetAsync(s.allow.p, 0xFF, (size_t)std::max(words, 1u) * 4, stream));
+        allow = (const uint32_t*)s.allow.p;
     }
     // The LDS visited set is sized for a typical search (hnsw_search.hip); what "typical" is depends on
     // the data.  Each launch reports how many queries outgrew it; when that was more than 2 % the
@@ -528,6 +550,14 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
         auto it = idx->hbits_bias.find((uint32_t)ef);
         work.hbits_bias = it == idx->hbits_bias.end() ? 0u : it->second;
     }
+    if (stop) {
+        uint32_t u;
+        std::memcpy(&u, &stop->epsilon, 4);
+        if (u == 0x80000000u) u = 0;  // -0.0 == +0.0
+        work.eps_ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        if (work.eps_ord == 0xFFFFFFFFu) work.eps_ord = 0xFFFFFFFEu;  // (unreachable for a non-NaN epsilon: +inf is 0xFF800000)
+        work.eps_min = (uint32_t)stop->min_num_candidates;
+    }
     if (fail_word) *fail_word = work.redo + 1;
     std::string err;
     const int rc = launch_hnsw_search(idx->graph, d_queries, (uint32_t)nq, (uint32_t)k, (uint32_t)ef, allow, d_out_dist,
@@ -542,7 +572,7 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
 }
 
 int search_host(vdb_index* idx, const float* queries, size_t nq, size_t k, const uint32_t* filter, float* out_dist,
-                uint64_t* out_label, uint32_t* out_stats) {
+                uint64_t* out_label, uint32_t* out_stats, const EpsilonStop* stop = nullptr) {
     require_search_ready(idx);
     if (nq == 0) return (int)VDB_OK;
     if (!queries || !out_dist || !out_label) throw std::invalid_argument("null buffer");
@@ -564,7 +594,7 @@ int search_host(vdb_index* idx, const float* queries, size_t nq, size_t k, const
     uint32_t* fail_word = nullptr;
     const int rc = search_device(idx, (const float*)st.q.p, nq, k, filter ? (const uint32_t*)st.filter.p : nullptr,
                                  (float*)st.dist.p, (uint64_t*)st.label.p, out_stats ? (uint32_t*)st.stats.p : nullptr, nullptr,
-                                 &fail_word);
+                                 &fail_word, stop);
     if (rc != VDB_OK) return rc;
     VDB_HIP(hipStreamSynchronize(nullptr));
     uint32_t failed = 0;
@@ -1106,6 +1136,25 @@ int vdb_search_batch_filtered(const vdb_index* idx, const float* queries, size_t
                               float* out_dist, uint64_t* out_label, uint32_t* out_stats) {
     return guarded([&] {
         return search_host(const_cast<vdb_index*>(idx), queries, nq, k, allow, out_dist, out_label, out_stats);
+    });
+}
+
+int vdb_search_epsilon_batch_device(const vdb_index* cidx, const float* d_queries, size_t nq, float epsilon,
+                                    size_t min_num_candidates, size_t max_num_candidates, const uint32_t* d_allow, float* d_out_dist,
+                                    uint64_t* d_out_label, uint32_t* d_out_stats, void* stream_) {
+    return guarded([&] {
+        const EpsilonStop stop{epsilon, min_num_candidates, max_num_candidates};
+        return search_device(const_cast<vdb_index*>(cidx), d_queries, nq, max_num_candidates, d_allow, d_out_dist, d_out_label,
+                             d_out_stats, (hipStream_t)stream_, nullptr, &stop);
+    });
+}
+
+int vdb_search_epsilon_batch(const vdb_index* idx, const float* queries, size_t nq, float epsilon, size_t min_num_candidates,
+                             size_t max_num_candidates, const uint32_t* allow, float* out_dist, uint64_t* out_label,
+                             uint32_t* out_stats) {
+    return guarded([&] {
+        const EpsilonStop stop{epsilon, min_num_candidates, max_num_candidates};
+        return search_host(const_cast<vdb_index*>(idx), queries, nq, max_num_candidates, allow, out_dist, out_label, out_stats, &stop);
     });
 }
 

@@ -300,6 +300,13 @@ struct KeyArray {
         }
         return full;
     }
+    // Number of allowed entries (the result set holds the first ef of them).
+    __device__ __forceinline__ uint32_t count_allowed() const {
+        uint32_t c = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) c += (uint32_t)__builtin_popcountll(ballot(hi[r] != kEmptyWord && (lo[r] & 2u) == 0u));
+        return c;
+    }
     // Behind the bound entry only keys AT the bound's distance can still be expanded (:316).
     __device__ __forceinline__ void trim_filtered(uint32_t bpos, uint32_t bound_hi, int lane) {
 #pragma unroll
@@ -330,6 +337,8 @@ struct SearchArgs {
     uint32_t* report;      // nullable, host-mapped: [0] = queries the fast configuration gave up on, [1] = nq
     uint32_t bitmap_words;
     uint32_t large_blocks; // grid of the large configuration (host side only)
+    uint32_t eps_ord;      // FILT only: the epsilon stop condition (HnswSearchWork), kEmptyWord = none
+    uint32_t eps_min;
 };
 
 // FILT = the non-bare searchBaseLayerST (hnsw_core.hpp:1141-1148 with deleted elements or a filter):
@@ -471,7 +480,21 @@ __global__ __launch_bounds__(64, (R <= 2 && !FILT && VIS != 2) ? 4 : 2) void hns
         uint32_t pfa_id = kNoId, pfb_id = kNoId, pfa_row = kNoId, pfb_row = kNoId;
         uint32_t cand;
 #pragma unroll 1
-        while (FILT ? arr.pop_candidate_filtered(lane, cand) : arr.pop_candidate(lane, cand)) {
+        while (true) {
+            if constexpr (FILT) {
+                // BaseSearchStopCondition::should_stop_search of the epsilon condition, asked before the candidate is
+                // taken (searchBaseLayerST with a stop condition): the best open candidate lies beyond
+                // epsilon and min_num_candidates results are held.  Its other clause (beyond the bound with the
+                // result set full) is what an empty candidate set means on this array.
+                if (a.eps_ord != kEmptyWord) {
+                    uint32_t pid, pd;
+                    if (arr.peek_candidate(pid, pd) && pd > a.eps_ord) {
+                        const uint32_t held = arr.count_allowed();
+                        if ((held < ef ? held : ef) >= a.eps_min) break;
+                    }
+                }
+            }
+            if (!(FILT ? arr.pop_candidate_filtered(lane, cand) : arr.pop_candidate(lane, cand))) break;
             hops0 += 1;
             if (nvis + g.l0stride > vis_limit) {
                 uint32_t more = 0;
@@ -588,7 +611,8 @@ __global__ __launch_bounds__(64, (R <= 2 && !FILT && VIS != 2) ? 4 : 2) void hns
         // `base` runs over the registers in order
         auto place_of = [&](int r, uint32_t& base) -> uint32_t {
             if constexpr (FILT) {
-                const bool ok = arr.hi[r] != kEmptyWord && (arr.lo[r] & 2u) == 0u;
+                // (filter_results of the epsilon condition: results beyond epsilon are dropped; they are the tail of the order)
+                const bool ok = arr.hi[r] != kEmptyWord && (arr.lo[r] & 2u) == 0u && arr.hi[r] <= a.eps_ord;
                 const uint64_t m = ballot(ok);
                 const uint32_t p = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 base += (uint32_t)__builtin_popcountll(m);
@@ -820,6 +844,12 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
     a.large_blocks = work.large_blocks ? work.large_blocks : 1u;
     a.ghash = work.ghash;
     a.report = work.report;
+    a.eps_ord = work.eps_ord;
+    a.eps_min = work.eps_min;
+    if (a.eps_ord != kEmptyWord && (!d_allow || k != ef)) {
+        if (err) *err = "hnsw_search: the stop condition needs the filtered path and k == ef";
+        return 1;
+    }
     hipError_t e = hipMemsetAsync(work.redo, 0, kRedoHeader * sizeof(uint32_t), stream);
     if (e != hipSuccess) {
         if (err) *err = std::string("hipMemsetAsync: ") + hipGetErrorString(e);

@@ -44,6 +44,12 @@ struct HnswSearchWork {
     uint32_t* bitmaps = nullptr;  // [large_blocks][bitmap_words]
     uint32_t bitmap_words = 0;
     uint32_t large_blocks = kLargeBlocks;  // resident waves of the large configuration (one bitmap each)
+    // searchStopConditionClosest (hnsw_core.hpp:1162-1213) with the epsilon-radius condition: stop once the best open
+    // candidate lies beyond eps and at least eps_min results are held; only results within eps are returned.  Filtered
+    // launches only (d_allow given; k = ef = the condition's max_num_candidates).  eps_ord = ordered u32 of epsilon,
+    // 0xFFFFFFFF = no stop condition.
+    uint32_t eps_ord = 0xFFFFFFFFu;
+    uint32_t eps_min = 0;
 };
 
 // Enqueues the search of nq queries on `stream` (two launches: fast configuration, then the

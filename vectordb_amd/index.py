@@ -232,6 +232,22 @@ class HierarchicalNSW:
                                                 st.ctypes.data_as(_u32p) if stats else None))
         return (dist, label, st) if stats else (dist, label)
 
+    def search_stop_condition_closest_batch(self, queries, epsilon: float, min_num_candidates: int, max_num_candidates: int,
+                                            filter=None):
+        """searchStopConditionClosest (hnsw_core.hpp:1162-1213) with the epsilon-radius stop condition, for every row of
+        `queries` (numpy, host path).  Returns (dist [nq, max], label [nq, max], count [nq], stats [nq, 4]): row q holds
+        count[q] results within `epsilon`, closest first, padded with +inf / UINT64_MAX."""
+        q = _as_f32(queries, self.space.dim)
+        nq, k = q.shape[0], int(max_num_candidates)
+        dist = np.empty((nq, k), np.float32)
+        label = np.empty((nq, k), np.uint64)
+        st = np.empty((nq, 4), np.uint32)
+        allow = np.frombuffer(self.filter_bitmap(filter), np.uint32) if filter is not None else None
+        check(self._l.vdb_search_epsilon_batch(self._h, q.ctypes.data_as(_f32p), nq, float(epsilon), int(min_num_candidates), k,
+                                               allow.ctypes.data_as(_u32p) if allow is not None else None,
+                                               dist.ctypes.data_as(_f32p), label.ctypes.data_as(_u64p), st.ctypes.data_as(_u32p)))
+        return dist, label, st[:, 3].copy(), st
+
     def search_batch_noalloc(self, queries, dist, label, stats=None) -> None:
         """vdb_search_batch_device_noalloc: CUDA tensors in, results into the caller's CUDA tensors
         (dist [nq,k] f32, label [nq,k] int64, stats nullable [nq,4] int32); nothing is allocated."""
