@@ -167,10 +167,14 @@ int vdb_search_batch(const vdb_index* idx, const float* queries, size_t nq, size
  *            i / 32 set = filter(label of element i) is true.  vdb_index_labels() gives the labels
  *            in internal-id order to evaluate the functor on.  NULL = no filter.
  * Deleted elements are excluded as well.  Nodes that are not allowed are still traversed (:340-343).
- * A query whose live candidates outside the result set outnumber what the kernel keeps (256-1024
- * keys by ef; a filter that rejects almost everything - use brute force there) is not answered
- * approximately: its output row is NaN / UINT64_MAX and stats.found = UINT32_MAX; the host-pointer
- * variant then returns VDB_ERR_UNSUPPORTED (the other rows are valid). */
+ * A query whose live candidates outside the result set outnumber what the register configurations keep
+ * (256-1024 keys by ef: a filter that rejects almost everything) is run once more with its candidates in
+ * a heap in HBM (hnsw_search_unbounded_kernel): answered as the reference's unbounded heaps would, only
+ * slowly (brute force over the allowed rows is the faster tool at such selectivity).  What remains
+ * reported instead of answered - row NaN / UINT64_MAX, stats.found = UINT32_MAX, VDB_ERR_UNSUPPORTED from
+ * the host-pointer variant (the other rows are valid): more than 2^25 candidates at once, and, on the
+ * unfiltered path and in vdb_search_batch_device_noalloc, hundreds of base vectors at exactly the
+ * distance of the ef-th result. */
 int vdb_search_batch_device_filtered(const vdb_index* idx, const float* d_queries, size_t nq, size_t k,
                                      const uint32_t* d_allow, float* d_out_dist, uint64_t* d_out_label,
                                      uint32_t* d_out_stats, void* stream);

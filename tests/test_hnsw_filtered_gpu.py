@@ -102,6 +102,9 @@ def test_filter_and_deleted_on_device_tensors(orc):
 
 
 def test_everything_filtered_out(orc):
+    """A filter that accepts nothing: every node is a candidate that is never a result, the search walks the whole
+    graph and returns nothing - as the reference's unbounded heaps do (hnsw_core.hpp:1141-1148).  On the device that is
+    the heap-in-HBM kernel behind the register configurations; counters equal the oracle's."""
     n, dim = 2000, 16
     x = datasets.uniform(n, dim, 69)
     q = datasets.uniform(20, dim, 70)
@@ -109,14 +112,41 @@ def test_everything_filtered_out(orc):
     h.to_device(0)
     h.setefSearch(20)
     o.set_ef(20)
-    try:
-        d, l = h.search_batch(q, 5, filter=np.zeros(n, bool))
-    except vi.VdbError as e:  # every node is a candidate that is never a result: may exceed the kernel's capacity
-        assert e.code == _lib.VDB_ERR_UNSUPPORTED
-        return
+    d, l, st = h.search_batch(q, 5, stats=True, filter=np.zeros(n, bool))
     assert (l == np.uint64(0xFFFFFFFFFFFFFFFF)).all() and np.isinf(d).all()
     r = o.search(q, 5, filter_mod=1, filter_keep=5)  # label % 1 == 5: never
     assert (r["count"] == 0).all()
+    assert_same_results((d, l), r, st)
+    assert (st[:, 0] >= n).all()  # every element was scored on layer 0 (plus the descent)
+
+
+@pytest.mark.parametrize("mod,ef,k", [(400, 10, 5), (1500, 64, 10), (97, 200, 100)])
+def test_extreme_selectivity_is_answered(orc, mod, ef, k):
+    """Filters that keep one element in `mod`: far more live candidates outside the result set than any register array
+    holds (the queries end up in hnsw_search_unbounded_kernel).  Answers and counters equal the oracle's bit for bit."""
+    n, dim = 12000, 24
+    x = datasets.clustered(n, dim, 81)
+    q = datasets.clustered(64, dim, 82)
+    h, o = build_pair(orc, x, n_threads=4)
+    for lab in range(0, n, 7):  # with deleted elements as well
+        h.markDelete(lab)
+        o.mark_delete(lab)
+    h.to_device(0)
+    h.setefSearch(ef)
+    o.set_ef(ef)
+    d, l, st = h.search_batch(q, k, stats=True, filter=lambda lab: lab % mod == 3)
+    r = o.search(q, k, filter_mod=mod, filter_keep=3)
+    assert_same_results((d, l), r, st)
+    found = l[l != np.uint64(0xFFFFFFFFFFFFFFFF)]
+    assert len(found) and (found % mod == 3).all() and (found % 7 != 0).all()
+    # and with the epsilon stop condition on top
+    eps = float(np.median(r["dist"][:, 0]) * 1.5)
+    de, le, cnt, ste = h.search_stop_condition_closest_batch(q, eps, 2, ef, filter=lambda lab: lab % mod == 3)
+    re = o.search_epsilon(q, eps, 2, ef, filter_mod=mod, filter_keep=3)
+    np.testing.assert_array_equal(cnt, re["count"])
+    np.testing.assert_array_equal(le, re["label"].astype(np.uint64))
+    np.testing.assert_array_equal(de.view(np.uint32), re["dist"].view(np.uint32))
+    np.testing.assert_array_equal(ste[:, 0], re["ndis"].astype(np.uint32))
 
 
 def test_device_against_committed_golden():

@@ -109,6 +109,8 @@ struct SearchScratch {
     DevBuf redo, bitmaps, allow;  // allow: delete flags AND the caller's filter, when both exist
     DevBuf ghash;                 // visited tables in HBM for the large-ef configuration (allocated on first need)
     DevBuf spill;                 // second-level visited tables for the queries that fill their LDS table
+    DevBuf heaps;                 // candidate heaps of hnsw_search_unbounded_kernel (filtered searches; allocated on first need)
+    uint32_t heap_cap = 0, heap_blocks = 0;
     uint32_t spill_tables = 0;
     // host-mapped {re-run queries, nq} written by the last launch on this stream, and the ef it ran at:
     // read (without synchronising) before the next launch to size the visited set (see search_device)
@@ -545,6 +547,22 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
         if (!s.ghash.p) s.ghash.alloc(((size_t)kGlobalHashBlocks << kGlobalHashBits) * 4);
         work.ghash = (uint32_t*)s.ghash.p;
     }
+    if (allow && idx->graph.n) {
+        // filtered searches: the queries that outgrow every key array are answered from a heap in HBM.  One heap holds
+        // every node of the graph at worst (a filter that accepts nothing walks the whole graph); at most 256 MB in all.
+        const uint32_t cap = (uint32_t)std::min<size_t>(idx->graph.n, (size_t)1 << 25);
+        if (s.heap_cap < cap) {
+            if (s.heaps.p) VDB_HIP(hipStreamSynchronize(stream));
+            const uint32_t blocks = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, ((size_t)256 << 20) / ((size_t)cap * 8)));
+            s.heaps.alloc((size_t)blocks * cap * 8);
+            s.heap_cap = cap;
+            s.heap_blocks = blocks;
+        }
+        work.heaps = (uint64_t*)s.heaps.p;
+        work.heap_cap = s.heap_cap;
+        work.heap_blocks = s.heap_blocks;
+        work.fail_list = work.redo + kRedoHeader + nq;  // the second half of the work list's buffer (scratch_for)
+    }
     work.report = arm_report ? s.report : nullptr;
     {
         auto it = idx->hbits_bias.find((uint32_t)ef);
@@ -558,7 +576,7 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
         if (work.eps_ord == 0xFFFFFFFFu) work.eps_ord = 0xFFFFFFFEu;  // (unreachable for a non-NaN epsilon: +inf is 0xFF800000)
         work.eps_min = (uint32_t)stop->min_num_candidates;
     }
-    if (fail_word) *fail_word = work.redo + 1;
+    if (fail_word) *fail_word = work.heaps ? work.redo + 3 : work.redo + 1;  // queries left unanswered
     std::string err;
     const int rc = launch_hnsw_search(idx->graph, d_queries, (uint32_t)nq, (uint32_t)k, (uint32_t)ef, allow, d_out_dist,
                                       d_out_label, d_out_stats, work, stream, &err);

@@ -339,6 +339,9 @@ struct SearchArgs {
     uint32_t large_blocks; // grid of the large configuration (host side only)
     uint32_t eps_ord;      // FILT only: the epsilon stop condition (HnswSearchWork), kEmptyWord = none
     uint32_t eps_min;
+    uint32_t* fail_list;   // nullable: queries the large configuration could not answer, for hnsw_search_unbounded_kernel
+    uint64_t* heaps;       // [heap_blocks][heap_cap]
+    uint32_t heap_cap, heap_blocks;
 };
 
 // FILT = the non-bare searchBaseLayerST (hnsw_core.hpp:1141-1148 with deleted elements or a filter):
@@ -456,8 +459,10 @@ __global__ __launch_bounds__(64, (R <= 2 && !FILT && VIS != 2) ? 4 : 2) void hns
         arr.clear();
         auto not_allowed = [&](uint32_t id) { return ((a.allow[id >> 5] >> (id & 31u)) & 1u) ^ 1u; };
         uint32_t bound;  // lowerBound once the result set is full, else "no bound"
+        bool ep_only_candidate = false;  // (:310 seeds it at "distance" -FLT_MAX: no stop condition fires on it)
         if constexpr (FILT) {
             const uint32_t dis = not_allowed(cur);  // :302-312: an entry point that is not allowed is a candidate only
+            ep_only_candidate = dis != 0;
             if (lane == 0) {
                 arr.hi[0] = cur_d;
                 arr.lo[0] = (cur << 2) | (dis << 1);
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(64, (R <= 2 && !FILT && VIS != 2) ? 4 : 2) void hns
                 // taken (searchBaseLayerST with a stop condition): the best open candidate lies beyond
                 // epsilon and min_num_candidates results are held.  Its other clause (beyond the bound with the
                 // result set full) is what an empty candidate set means on this array.
-                if (a.eps_ord != kEmptyWord) {
+                if (a.eps_ord != kEmptyWord && !(hops0 == 0 && ep_only_candidate)) {
                     uint32_t pid, pd;
                     if (arr.peek_candidate(pid, pd) && pd > a.eps_ord) {
                         const uint32_t held = arr.count_allowed();
@@ -591,7 +596,8 @@ __global__ __launch_bounds__(64, (R <= 2 && !FILT && VIS != 2) ? 4 : 2) void hns
                     ol[i] = ~0ull;
                 }
                 if (lane == 0) {
-                    atomicAdd(&a.redo[1], 1u);
+                    const uint32_t slot = atomicAdd(&a.redo[1], 1u);
+                    if (a.fail_list) a.fail_list[slot] = qi;  // answered by hnsw_search_unbounded_kernel after this launch
                     if (a.out_stats) {
                         uint32_t* st = a.out_stats + (size_t)qi * 4;
                         st[kStatNdis] = ndis;
@@ -687,6 +693,244 @@ __global__ __launch_bounds__(64, (R <= 2 && !FILT && VIS != 2) ? 4 : 2) void hns
     }
 }
 
+// ------------------------------------------------------------------ the search without a capacity limit
+//
+// The queries the large configuration gave up on (a filter that rejects almost every node: the candidates that are not
+// results outnumber any register array; the reference's two std::priority_queues have no limit, hnsw_core.hpp:1141-1148).
+// A literal restatement of the non-bare searchBaseLayerST instead of the one-array design: the candidate set is a
+// 64-ary min-heap of (ordered distance << 32 | id) keys in HBM (one wave: a sift-down compares the 64 children of a
+// node in one step), the result set a sorted array of at most ef keys in LDS, the visited set the large
+// configuration's bitmap.  Same distances (score_nodes), same order of admission, same counters: bit-identical to the
+// oracle, just slow (every heap step is an L2 round trip) - it exists so that no query goes unanswered.
+struct HbmHeap {
+    uint64_t* h;
+    uint32_t size, cap;
+    // (agent-scope accesses: L2, not this CU's L1, which another lane's store does not refresh)
+    static __device__ __forceinline__ uint64_t ld(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    static __device__ __forceinline__ void st(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ bool push(uint64_t key, int lane) {  // key wave-uniform
+        if (size >= cap) return false;
+        uint32_t pos = size++;
+        while (pos > 0) {
+            const uint32_t par = (pos - 1u) >> 6;
+            const uint64_t pk = ld(h + par);
+            if (pk <= key) break;
+            if (lane == 0) st(h + pos, pk);
+            pos = par;
+        }
+        if (lane == 0) st(h + pos, key);
+        return true;
+    }
+    __device__ __forceinline__ uint64_t top() const { return ld(h); }
+    __device__ __forceinline__ void pop(int lane) {  // size > 0
+        const uint64_t last = ld(h + --size);
+        uint32_t pos = 0;
+        while (true) {
+            const uint32_t c = 64u * pos + 1u;
+            if (c >= size) break;
+            const uint64_t ck = c + (uint32_t)lane < size ? ld(h + c + lane) : ~0ull;
+            const uint32_t mh = wave_min_u32((uint32_t)(ck >> 32));
+            const uint32_t ml = wave_min_u32((uint32_t)(ck >> 32) == mh ? (uint32_t)ck : kEmptyWord);
+            const uint64_t mk = ((uint64_t)mh << 32) | ml;
+            if (mk >= last) break;
+            const int ml_lane = __builtin_ctzll(ballot(ck == mk));
+            if (lane == 0) st(h + pos, mk);
+            pos = c + (uint32_t)ml_lane;
+        }
+        if (lane == 0) st(h + pos, last);
+    }
+};
+
+constexpr uint32_t kUnbResults = 512;  // >= kMaxEf + 1
+
+template <int NCH, int GPB, bool IS_L2>
+__global__ __launch_bounds__(64) void hnsw_search_unbounded_kernel(SearchArgs a) {
+    __shared__ uint64_t s_res[kUnbResults];  // the result set, ascending (ordered dist << 32 | id)
+    __shared__ uint64_t s_lab[kUnbResults];
+    const int lane = lane_id();
+    const DevGraph& g = a.g;
+    BitmapVisited vis;
+    vis.bits = a.bitmaps + (size_t)blockIdx.x * a.bitmap_words;
+    vis.words = a.bitmap_words;
+    HbmHeap heap;
+    heap.h = a.heaps + (size_t)blockIdx.x * a.heap_cap;
+    heap.cap = a.heap_cap;
+    const uint32_t n_work = a.redo[1];
+    auto not_allowed = [&](uint32_t id) { return a.allow ? ((a.allow[id >> 5] >> (id & 31u)) & 1u) ^ 1u : 0u; };
+#pragma unroll 1
+    for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const uint32_t qi = a.fail_list[w];
+        const uint32_t k = a.k, ef = a.ef;
+        float* od = a.out_dist + (size_t)qi * k;
+        uint64_t* ol = a.out_label + (size_t)qi * k;
+        uint32_t ndis = 0, hops0 = 0, hops_up = 0;
+        f32x4 q[NCH];
+        {
+            const float* qp = a.queries + (size_t)qi * g.dim;
+            const int t = lane & 15;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                float e[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t pos = (uint32_t)(64 * j + 4 * t + c);
+                    e[c] = pos < g.dim ? qp[pos] : 0.f;
+                }
+                q[j] = f32x4{e[0], e[1], e[2], e[3]};
+            }
+        }
+        vis.clear(lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_wave_barrier();
+
+        // entry point and greedy descent, hnsw_core.hpp:1111-1138 (as in hnsw_search_kernel)
+        uint32_t cur = g.entry;
+        uint32_t cur_d = readlane(score_nodes<NCH, GPB, IS_L2>(g, q, cur, 1u, lane), 0);
+        ndis += 1;
+        uint32_t cur_row = g.max_level > 0 ? g.upper_row[cur] : 0u;
+        for (int level = g.max_level; level > 0; --level) {
+            bool changed = true;
+            while (changed) {
+                changed = false;
+                const uint32_t row = cur_row + (uint32_t)(level - 1);
+                const uint32_t nb = (uint32_t)lane < g.ustride ? g.upper_links[(size_t)row * g.ustride + lane] : kNoId;
+                const uint32_t nb_row = nb != kNoId ? g.upper_row[nb] : 0u;
+                const uint32_t n = (uint32_t)__builtin_popcountll(ballot(nb != kNoId));
+                hops_up += 1;
+                ndis += n;
+                if (n == 0) break;
+                uint32_t d = score_nodes<NCH, GPB, IS_L2>(g, q, nb, n, lane);
+                if ((uint32_t)lane >= n) d = kEmptyWord;
+                const uint32_t bd = wave_min_u32(d);
+                if (bd < cur_d) {
+                    cur_d = bd;
+                    const int bl = __builtin_ctzll(ballot(d == bd));
+                    cur = readlane(nb, bl);
+                    cur_row = readlane(nb_row, bl);
+                    changed = true;
+                }
+            }
+        }
+
+        // layer 0: the oracle's searchBaseLayerST<false>, line by line
+        uint32_t nres = 0;
+        heap.size = 0;
+        auto wave_lds_sync = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        };
+        auto res_insert = [&](uint64_t key) {  // top.emplace(d, id); if (top.size() > ef) top.pop();
+            uint32_t pos = 0;
+            for (uint32_t base = 0; base < nres; base += 64) {
+                const uint32_t j = base + (uint32_t)lane;
+                pos += (uint32_t)__builtin_popcountll(ballot(j < nres && s_res[j] < key));
+            }
+            for (int base = (int)((nres + 63u) & ~63u) - 64; base >= 0; base -= 64) {
+                const uint32_t j = (uint32_t)base + (uint32_t)lane;
+                const bool mv = j < nres && j >= pos && j + 1u < kUnbResults;
+                const uint64_t v = mv ? s_res[j] : 0ull;
+                wave_lds_sync();
+                if (mv) s_res[j + 1u] = v;
+                wave_lds_sync();
+            }
+            if (lane == 0) s_res[pos] = key;
+            wave_lds_sync();
+            nres += 1;
+            if (nres > ef) nres = ef;
+        };
+        bool failed = false;
+        const bool ep_only_candidate = not_allowed(cur) != 0;  // (:310 seeds it at "distance" -FLT_MAX: no stop condition fires on it)
+        {
+            const uint64_t key = ((uint64_t)cur_d << 32) | cur;
+            (void)heap.push(key, lane);  // (cap >= 1)
+            if (!ep_only_candidate) res_insert(key);
+            if (lane == 0) (void)vis.test_and_set(cur);
+        }
+#pragma unroll 1
+        while (heap.size > 0) {
+            const uint64_t ck = heap.top();
+            const uint32_t cd = (uint32_t)(ck >> 32), cand = (uint32_t)ck;
+            const uint32_t lb = nres ? (uint32_t)(s_res[nres - 1u] >> 32) : kEmptyWord;
+            if (cd > lb && nres == ef) break;                                        // :316
+            if (a.eps_ord != kEmptyWord && cd > a.eps_ord && nres >= a.eps_min && !(hops0 == 0 && ep_only_candidate)) break;  // epsilon condition
+            heap.pop(lane);
+            hops0 += 1;
+            const uint32_t nb = (uint32_t)lane < g.l0stride ? g.links0[(size_t)cand * g.l0stride + lane] : kNoId;
+            const bool fresh = nb != kNoId && vis.test_and_set(nb);
+            const uint64_t fm = ballot(fresh);
+            const uint32_t m_all = (uint32_t)__builtin_popcountll(fm);
+            if (m_all == 0) continue;
+            ndis += m_all;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+            const uint32_t dest = fresh ? rank : m_all + ((uint32_t)lane - rank);
+            const uint32_t ids_c = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)(fresh ? nb : kNoId));
+#pragma unroll 1
+            for (uint32_t c0 = 0; c0 < m_all && !failed; c0 += 32) {
+                const uint32_t m = m_all - c0 < 32u ? m_all - c0 : 32u;
+                const uint32_t ids_part = c0 == 0 ? ids_c : bpermute(ids_c, (lane + 32) & 63);
+                const uint32_t dis = (uint32_t)lane < m ? not_allowed(ids_part) : 0u;
+                uint32_t dord = score_nodes<NCH, GPB, IS_L2>(g, q, ids_part, m, lane);
+                if ((uint32_t)lane >= m) dord = kEmptyWord;
+                // sequential admission in list order with the evolving bound, :339-349
+                for (uint32_t r = 0; r < m; ++r) {
+                    const uint32_t d = readlane(dord, (int)r);
+                    const uint32_t bound = nres ? (uint32_t)(s_res[nres - 1u] >> 32) : kEmptyWord;
+                    if (nres < ef || bound > d) {
+                        const uint64_t key = ((uint64_t)d << 32) | readlane(ids_part, (int)r);
+                        if (!heap.push(key, lane)) {
+                            failed = true;
+                            break;
+                        }
+                        if (!readlane(dis, (int)r)) res_insert(key);
+                    }
+                }
+            }
+            if (failed) break;
+        }
+        if (failed) {  // more candidates than heap_cap: the row stays as the large configuration reported it
+            if (lane == 0) atomicAdd(&a.redo[3], 1u);
+            continue;
+        }
+
+        // epilogue, hnsw_core.hpp:1150-1158: the k smallest by (dist, id), ordered by (dist, label); with the stop
+        // condition only those within epsilon
+        uint32_t kout = nres < k ? nres : k;
+        {
+            uint32_t within = 0;
+            for (uint32_t base = 0; base < kout; base += 64) {
+                const uint32_t j = base + (uint32_t)lane;
+                within += (uint32_t)__builtin_popcountll(ballot(j < kout && (uint32_t)(s_res[j] >> 32) <= a.eps_ord));
+            }
+            kout = within;
+        }
+        for (uint32_t j = lane; j < kout; j += 64) s_lab[j] = g.labels[(uint32_t)s_res[j]];
+        wave_lds_sync();
+        for (uint32_t j = lane; j < kout; j += 64) {
+            const uint32_t hj = (uint32_t)(s_res[j] >> 32);
+            const uint64_t lj = s_lab[j];
+            uint32_t pos = 0;
+            for (uint32_t i = 0; i < kout; ++i) {
+                const uint32_t hi_i = (uint32_t)(s_res[i] >> 32);
+                pos += (hi_i < hj || (hi_i == hj && s_lab[i] < lj)) ? 1u : 0u;
+            }
+            od[pos] = ord2f(hj);
+            ol[pos] = lj;
+        }
+        for (uint32_t i = kout + lane; i < k; i += 64) {
+            od[i] = __builtin_inff();
+            ol[i] = ~0ull;
+        }
+        if (a.out_stats && lane == 0) {
+            uint32_t* st = a.out_stats + (size_t)qi * 4;
+            st[kStatNdis] = ndis;
+            st[kStatHops0] = hops0;
+            st[kStatHopsUpper] = hops_up;
+            st[kStatFound] = kout;
+        }
+        wave_lds_sync();
+    }
+}
+
 __global__ __launch_bounds__(256) void and_bitmaps_kernel(const uint32_t* a, const uint32_t* b, uint32_t* out, uint32_t words) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < words) out[i] = a[i] & b[i];
@@ -758,6 +1002,15 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
         else
             hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, RL, 2, false, FILT>), dim3(blocks), dim3(64),
                                (size_t)64 * RL * 12, stream, a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && a.fail_list && a.heaps && a.heap_blocks) {
+        uint32_t blocks = a.heap_blocks < a.large_blocks ? a.heap_blocks : a.large_blocks;
+        if (a.nq < blocks) blocks = a.nq;
+        if (a.g.metric == 0)
+            hipLaunchKernelGGL((hnsw_search_unbounded_kernel<NCH, GPB, true>), dim3(blocks), dim3(64), 0, stream, a);
+        else
+            hipLaunchKernelGGL((hnsw_search_unbounded_kernel<NCH, GPB, false>), dim3(blocks), dim3(64), 0, stream, a);
         e = hipGetLastError();
     }
     if (e != hipSuccess) {
@@ -846,6 +1099,11 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
     a.report = work.report;
     a.eps_ord = work.eps_ord;
     a.eps_min = work.eps_min;
+    const bool unbounded = d_allow && work.fail_list && work.heaps && work.heap_cap && work.heap_blocks;
+    a.fail_list = unbounded ? work.fail_list : nullptr;
+    a.heaps = unbounded ? work.heaps : nullptr;
+    a.heap_cap = unbounded ? work.heap_cap : 0u;
+    a.heap_blocks = unbounded ? work.heap_blocks : 0u;
     if (a.eps_ord != kEmptyWord && (!d_allow || k != ef)) {
         if (err) *err = "hnsw_search: the stop condition needs the filtered path and k == ef";
         return 1;

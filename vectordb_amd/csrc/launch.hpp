@@ -50,6 +50,14 @@ struct HnswSearchWork {
     // 0xFFFFFFFF = no stop condition.
     uint32_t eps_ord = 0xFFFFFFFFu;
     uint32_t eps_min = 0;
+    // Filtered searches whose live candidates outgrow even the large configuration's key array (a filter that rejects
+    // almost everything) are run once more by hnsw_search_unbounded_kernel: candidates in a heap in HBM, no limit but
+    // heap_cap.  fail_list [nq] u32 (query ids, counted in redo[1]); heaps [heap_blocks][heap_cap] u64; heap_blocks <=
+    // large_blocks (it reuses their bitmaps).  Without them such queries are reported (redo[1], NaN rows); with them
+    // redo[3] counts the queries that outgrew heap_cap as well.
+    uint32_t* fail_list = nullptr;
+    uint64_t* heaps = nullptr;
+    uint32_t heap_cap = 0, heap_blocks = 0;
 };
 
 // Enqueues the search of nq queries on `stream` (two launches: fast configuration, then the
