@@ -128,6 +128,14 @@ int vdb_index_links(const vdb_index* idx, uint32_t internal_id, int level, uint3
 /* Repack the host graph into the HBM layout and upload it to `device` (no reference
  * counterpart: the reference has no device).  Must be called again after add/delete. */
 int vdb_index_to_device(vdb_index* idx, int device);
+/* loadIndex (hnsw_core.hpp:581-682) followed by vdb_index_to_device, without the host copy of the level-0 block
+ * in between: the header, the levels and the upper-layer lists (a few percent of the file) are read first, then
+ * the rows [list | vector | label] stream from the file in 64 Ki-row chunks through the same repack, validation
+ * and upload as vdb_index_to_device (identical device image; a 65 GB index needs ~100 MB of host memory, not
+ * 65 GB).  The index it returns searches (every vdb_search_* entry point, efSearch, stats) and can be
+ * uploaded again; what needs the rows on the host - add, markDelete, save, resize, links of layer 0, labels,
+ * integrity check - fails with VDB_ERR_RUNTIME and says so: use vdb_index_load for those. */
+int vdb_index_load_to_device(vdb_index** out, const char* path, int metric, size_t dim, int device);
 /* Bytes the device copy occupies (0 if not uploaded). */
 size_t vdb_index_device_bytes(const vdb_index* idx);
 

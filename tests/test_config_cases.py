@@ -143,3 +143,43 @@ def test_c4_like_inner_product_shards(orc):
     bf.to_device(0)
     _, truth = bf.search_batch(q, k)
     assert datasets.recall_at_k(ml.cpu().numpy().view(np.uint64), truth) >= 0.95
+
+
+@pytest.mark.gpu
+def test_streamed_load_equals_two_step_load(orc, tmp_path):
+    """vdb_index_load_to_device (row N2: loadIndex hnsw_core.hpp:581-682 without the host copy of the level-0 block):
+    same device image size, same answers and counters as load + to_device, deleted elements and a filter included;
+    what needs host rows says so."""
+    n, dim = 70_000, 48   # more than one 65 536-row chunk
+    x = datasets.clustered(n, dim, 91)
+    q = datasets.clustered(500, dim, 92)
+    labels = np.arange(n, dtype=np.uint64) * 3 + 11
+    h = vi.HierarchicalNSW(vi.L2Space(dim), n, 12, 80)
+    h.add_items(x, labels, n_threads=8)
+    for lab in labels[::9]:
+        h.markDelete(int(lab))
+    path = str(tmp_path / "big.bin")
+    h.saveIndex(path)
+    two = vi.HierarchicalNSW(vi.L2Space(dim), location=path)
+    two.to_device(0)
+    one = vi.HierarchicalNSW(vi.L2Space(dim), location=path, stream_to_device=0)
+    assert one.device_bytes() == two.device_bytes() and one.getElementCount() == n
+    assert one.getDeletedCount() == two.getDeletedCount() == len(labels[::9])
+    for ef, k, filt in [(40, 10, None), (120, 30, lambda lab: lab % 5 == 1)]:
+        one.setefSearch(ef)
+        two.setefSearch(ef)
+        bitmap = None if filt is None else np.array([filt(int(l)) for l in labels])  # (labels() needs host rows)
+        d1, l1, s1 = one.search_batch(q, k, stats=True, filter=bitmap)
+        d2, l2, s2 = two.search_batch(q, k, stats=True, filter=bitmap)
+        np.testing.assert_array_equal(l1, l2)
+        np.testing.assert_array_equal(d1.view(np.uint32), d2.view(np.uint32))
+        np.testing.assert_array_equal(s1, s2)
+    o = orc.OracleHNSW.load(path, orc.L2, dim, mode=orc.TREE64)
+    o.set_ef(120)
+    r = o.search(q[:100], 30)
+    d1, l1 = one.search_batch(q[:100], 30)
+    np.testing.assert_array_equal(l1, r["label"].astype(np.uint64))
+    for call in (lambda: one.saveIndex(path + "2"), lambda: one.markDelete(int(labels[1])), lambda: one.labels(),
+                 lambda: one.addPoint(x[0], 10**9)):
+        with pytest.raises(vi.VdbError, match="loaded straight to the device"):
+            call()

@@ -59,6 +59,7 @@ SIGNATURES = {
     "vdb_search_batch_filtered": (C.c_int, [_vp, _f32p, C.c_size_t, C.c_size_t, _u32p, _f32p, _u64p, _u32p]),
     "vdb_search_epsilon_batch_device": (C.c_int, [_vp, _vp, C.c_size_t, C.c_float, C.c_size_t, C.c_size_t, _vp, _vp, _vp, _vp, _vp]),
     "vdb_search_epsilon_batch": (C.c_int, [_vp, _f32p, C.c_size_t, C.c_float, C.c_size_t, C.c_size_t, _u32p, _f32p, _u64p, _u32p]),
+    "vdb_index_load_to_device": (C.c_int, [C.POINTER(_vp), C.c_char_p, C.c_int, C.c_size_t, C.c_int]),
     "vdb_index_labels": (C.c_int, [_vp, _u64p, C.c_size_t]),
     "vdb_bf_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_size_t, C.c_size_t]),
     "vdb_bf_load": (C.c_int, [C.POINTER(_vp), C.c_char_p, C.c_int, C.c_size_t]),

@@ -119,6 +119,15 @@ public:
         : device_(device) {
         vdb_check(vdb_index_load(&idx_, location.c_str(), s->metric, s->dim, capacity));
     }
+    // The load constructor without the host copy of the level-0 block (vdb_index_load_to_device): for indexes that are
+    // only searched.  `HierarchicalNSW big(&space, path, HierarchicalNSW::StreamToDevice{0});`
+    struct StreamToDevice {
+        int device = 0;
+    };
+    HierarchicalNSW(const SpaceInterface* s, const std::string& location, StreamToDevice to) : device_(to.device) {
+        vdb_check(vdb_index_load_to_device(&idx_, location.c_str(), s->metric, s->dim, to.device));
+        dirty_ = false;
+    }
     ~HierarchicalNSW() override { vdb_index_free(idx_); }
     HierarchicalNSW(const HierarchicalNSW&) = delete;
     HierarchicalNSW& operator=(const HierarchicalNSW&) = delete;

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <map>
 #include <set>
 #include <memory>
@@ -324,7 +325,19 @@ void upload(vdb_index* idx, int device) {
         }
     };
 
+    // Rows come from the host copy, or - an index opened by vdb_index_load_to_device - straight from the file, one
+    // chunk at a time (hnsw_core.hpp:581-682 reads the whole block into memory first; a 65 GB index need not).
     const size_t chunk = 1 << 16;
+    std::ifstream rows_in;
+    std::vector<char> rows_buf;
+    if (!h.rows_resident) {
+        rows_in.open(h.rows_path, std::ios::binary);
+        if (!rows_in.is_open()) throw std::runtime_error("Cannot open file");
+        rows_in.seekg((std::streamoff)h.rows_offset, rows_in.beg);
+        rows_buf.resize(chunk * h.stride);
+    }
+    std::vector<uint32_t> live((n + 31) / 32, 0u);
+    size_t n_deleted = 0;
     std::vector<float> sv(chunk * vstride);
     std::vector<uint32_t> sl(chunk * l0stride);
     std::vector<uint64_t> slab(chunk);
@@ -340,6 +353,15 @@ void upload(vdb_index* idx, int device) {
         size_t urow_hi = urow_lo;
         for (size_t i = lo; i < lo + m; ++i) urow_hi += (size_t)std::max(h.levels[i], 0);
         su.assign((urow_hi - urow_lo) * ustride, kNoId);
+        const char* rows = h.rows_resident ? h.level0 + lo * h.stride : rows_buf.data();
+        if (!h.rows_resident) {
+            rows_in.read(rows_buf.data(), (std::streamsize)(m * h.stride));
+            if (!rows_in.good()) throw std::runtime_error("Index seems to be corrupted or unsupported");
+        }
+        for (size_t i = 0; i < m; ++i) {  // delete flag: byte +2 of the count word, hnsw_core.hpp:784-787
+            if (((const unsigned char*)(rows + i * h.stride + h.link0_off))[2] & 0x01) n_deleted += 1;
+            else live[(lo + i) >> 5] |= 1u << ((lo + i) & 31);
+        }
 
         std::atomic<bool> bad{false};
         std::string bad_msg;
@@ -349,15 +371,16 @@ void upload(vdb_index* idx, int device) {
                 for (size_t i = a; i < b; ++i) {
                     const uint32_t id = (uint32_t)(lo + i);
                     float* dv = sv.data() + i * vstride;
-                    std::memcpy(dv, h.vec(id), h.dim * 4);
+                    const char* r = rows + i * h.stride;
+                    std::memcpy(dv, r + h.data_off, h.dim * 4);
                     std::fill(dv + h.dim, dv + vstride, 0.f);
-                    const uint32_t* l0 = h.list0(id);
+                    const uint32_t* l0 = (const uint32_t*)(r + h.link0_off);
                     const unsigned c0 = HostIndex::list_count(l0);
                     check_list(l0 + 1, c0, h.maxM0, 0);
                     uint32_t* dl = sl.data() + i * l0stride;
                     std::copy(l0 + 1, l0 + 1 + c0, dl);
                     std::fill(dl + c0, dl + l0stride, kNoId);
-                    slab[i] = h.label_of(id);
+                    std::memcpy(&slab[i], r + h.label_off, 8);
                     for (int lv = 1; lv <= h.levels[id]; ++lv) {
                         const uint32_t* ul = h.list_at(id, lv);
                         const unsigned cu = HostIndex::list_count(ul);
@@ -389,10 +412,8 @@ void upload(vdb_index* idx, int device) {
                               hipMemcpyHostToDevice));
     }
     if (n) VDB_HIP(hipMemcpy(idx->upper_row.p, up_row.data(), n * 4, hipMemcpyHostToDevice));
-    if (h.deleted != 0) {  // delete flags (byte +2 of the count word, hnsw_core.hpp:784-787) as a bitmap of LIVE elements
-        std::vector<uint32_t> live((n + 31) / 32, 0u);
-        for (size_t i = 0; i < n; ++i)
-            if (!h.is_deleted((uint32_t)i)) live[i >> 5] |= 1u << (i & 31);
+    if (!h.rows_resident) idx->host->deleted = n_deleted;
+    if (n_deleted != 0) {  // the delete flags as a bitmap of LIVE elements
         idx->live.alloc(live.size() * 4);
         VDB_HIP(hipMemcpy(idx->live.p, live.data(), live.size() * 4, hipMemcpyHostToDevice));
     }
@@ -1069,6 +1090,7 @@ int vdb_index_level_of(const vdb_index* idx, uint32_t id) {
 }
 int vdb_index_links(const vdb_index* idx, uint32_t id, int level, uint32_t* out, int cap) {
     if (!idx || id >= idx->host->count || level < 0 || level > idx->host->levels[id]) return -1;
+    if (level == 0) idx->host->require_rows("get_linklist0");
     const uint32_t* list = idx->host->list_at(id, level);
     const int n = (int)HostIndex::list_count(list);
     for (int i = 0; i < n && i < cap; ++i) out[i] = list[1 + i];
@@ -1079,6 +1101,18 @@ int vdb_index_to_device(vdb_index* idx, int device) {
     return guarded([&] {
         if (!idx) throw std::invalid_argument("null index");
         upload(idx, device);
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_index_load_to_device(vdb_index** out, const char* path, int metric, size_t dim, int device) {
+    return guarded([&] {
+        if (!out || !path) throw std::invalid_argument("null argument");
+        if (metric != VDB_L2 && metric != VDB_IP) throw std::invalid_argument("unknown metric");
+        std::unique_ptr<vdb_index> idx(new vdb_index);
+        idx->host.reset(new HostIndex(std::string(path), metric, dim, 0, /*stream_rows=*/true));
+        upload(idx.get(), device);
+        *out = idx.release();
         return (int)VDB_OK;
     });
 }
@@ -1180,6 +1214,7 @@ int vdb_index_labels(const vdb_index* idx, uint64_t* out, size_t cap) {
     return guarded([&] {
         if (!idx || !out) throw std::invalid_argument("null argument");
         const size_t n = idx->host->count;
+        idx->host->require_rows("getExternalLabel");
         if (cap < n) throw std::invalid_argument("label buffer smaller than the element count");
         for (size_t i = 0; i < n; ++i) out[i] = idx->host->label_of((uint32_t)i);
         return (int)VDB_OK;

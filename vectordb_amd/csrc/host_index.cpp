@@ -54,10 +54,10 @@ void HostIndex::init_layout() {  // :140-152, :176-178
     level_lambda = 1.0 / std::log(1.0 * (double)M);
 }
 
-void HostIndex::alloc_storage(size_t cap) {
-    level0 = (char*)std::malloc(std::max<size_t>(cap * stride, 1));
+void HostIndex::alloc_storage(size_t cap, bool with_rows) {
+    level0 = with_rows ? (char*)std::malloc(std::max<size_t>(cap * stride, 1)) : nullptr;
     upper = (char**)std::calloc(std::max<size_t>(cap, 1), sizeof(char*));
-    if (!level0 || !upper) {
+    if ((with_rows && !level0) || !upper) {
         std::free(level0);
         std::free(upper);
         level0 = nullptr;
@@ -318,6 +318,7 @@ void HostIndex::insert(uint32_t id, const float* v, int level, BuildScratch& sc)
 }
 
 void HostIndex::add(const float* v, uint64_t label, int level) {
+    require_rows("addPoint");
     uint64_t l = label;
     add_batch(v, &l, 1, 1, level);
 }
@@ -325,6 +326,7 @@ void HostIndex::add(const float* v, uint64_t label, int level) {
 // Ids, levels and rows of n new elements, assigned in input order exactly as n sequential addPoint
 // calls would (:1018-1043); nothing is linked yet.  Returns the first new id.
 size_t HostIndex::append_unlinked(const float* vecs, const uint64_t* labels, size_t n, int forced_level, const int* given_levels) {
+    require_rows("addPoint");
     const size_t base = count;
     if (base + n > capacity) throw std::runtime_error("The number of elements exceeds the specified limit");  // :1018-1020
     {
@@ -363,6 +365,7 @@ void HostIndex::alloc_upper_lists(uint32_t id) {
 
 // addPoint's linking (:1044-1103) for elements that append_unlinked stored, in the order given.
 void HostIndex::link_elements(const uint32_t* ids, size_t n, int n_threads) {
+    require_rows("addPoint");
     if (n == 0) return;
     std::atomic<size_t> next{0};
     std::atomic<bool> failed{false};
@@ -400,6 +403,7 @@ void HostIndex::link_elements(const uint32_t* ids, size_t n, int n_threads) {
 }
 
 void HostIndex::truncate_to_empty() {
+    require_rows("addPoint");
     const size_t n = count;
     for (size_t i = 0; i < n; ++i) {
         if (upper[i]) std::free(upper[i]);
@@ -428,6 +432,7 @@ void HostIndex::add_batch(const float* vecs, const uint64_t* labels, size_t n, i
 // ------------------------------------------------------------------------------ persistence
 
 void HostIndex::save(const std::string& path) const {  // :551-579
+    require_rows("saveIndex");
     std::ofstream out(path, std::ios::binary);
     if (!out.is_open()) throw std::runtime_error("Cannot open file");
     const size_t n = count;
@@ -453,7 +458,7 @@ void HostIndex::save(const std::string& path) const {  // :551-579
     if (!out.good()) throw std::runtime_error("write failed");
 }
 
-HostIndex::HostIndex(const std::string& path, int metric_, size_t dim_, size_t capacity_hint) {  // :581-682
+HostIndex::HostIndex(const std::string& path, int metric_, size_t dim_, size_t capacity_hint, bool stream_rows) {  // :581-682
     metric = metric_;
     dim = dim_;
     std::ifstream in(path, std::ios::binary);
@@ -499,14 +504,22 @@ HostIndex::HostIndex(const std::string& path, int metric_, size_t dim_, size_t c
     size_t cap = capacity_hint;
     if (cap < n) cap = file_cap;
     if (cap < n) cap = n;
-    alloc_storage(cap);
-    in.read(level0, (std::streamsize)(n * stride));
+    if (stream_rows) {  // the level-0 block stays in the file: the uploader reads it (capi.cpp upload)
+        rows_resident = false;
+        rows_path = path;
+        rows_offset = (long long)pos;
+        alloc_storage(n, false);
+        in.seekg(pos + (std::streamoff)(n * stride), in.beg);
+    } else {
+        alloc_storage(cap);
+        in.read(level0, (std::streamsize)(n * stride));
+    }
     level_lambda = 1.0 / std::log(1.0 * (double)M);  // the reference forgets this (:654)
     ef_search = 10;                                  // :655
     rng_.seed(100);
     count = n;
     for (size_t i = 0; i < n; ++i) {
-        label_map_[label_of((uint32_t)i)] = (uint32_t)i;
+        if (rows_resident) label_map_[label_of((uint32_t)i)] = (uint32_t)i;
         unsigned bytes = 0;
         get(in, bytes);
         if (bytes == 0) {
@@ -520,8 +533,9 @@ HostIndex::HostIndex(const std::string& path, int metric_, size_t dim_, size_t c
         }
     }
     size_t del = 0;
-    for (size_t i = 0; i < n; ++i) del += is_deleted((uint32_t)i);
-    deleted = del;
+    if (rows_resident)
+        for (size_t i = 0; i < n; ++i) del += is_deleted((uint32_t)i);
+    deleted = del;  // (streamed rows: counted by the uploader)
     // searchKnn starts at entry_id_ on max_level_ (:1111-1114) without looking: a file that names an entry
     // point outside the index, or one without that many levels, is corrupt (link targets are validated per
     // level when the graph is repacked for the device, capi.cpp upload)
@@ -535,6 +549,7 @@ HostIndex::HostIndex(const std::string& path, int metric_, size_t dim_, size_t c
 // ------------------------------------------------------------------------------ maintenance
 
 void HostIndex::mark_delete(uint64_t label, bool undo) {  // :709-782
+    require_rows("markDelete");
     uint32_t id;
     {
         std::unique_lock<std::mutex> g(label_lock_);
@@ -556,6 +571,7 @@ void HostIndex::mark_delete(uint64_t label, bool undo) {  // :709-782
 }
 
 void HostIndex::resize(size_t new_cap) {  // :500-522
+    require_rows("resizeIndex");
     if (new_cap < count) throw std::runtime_error("Cannot resize, max element is less than the current number of elements");
     char* l0 = (char*)std::realloc(level0, std::max<size_t>(new_cap * stride, 1));
     if (!l0) throw std::runtime_error("Not enough memory: resizeIndex failed to allocate base layer");
@@ -571,6 +587,7 @@ void HostIndex::resize(size_t new_cap) {  // :500-522
 }
 
 int HostIndex::check_integrity(int* min_in, int* max_in) const {  // :1216-1245
+    require_rows("checkIntegrity");
     const size_t n = count;
     std::vector<int> inbound(n, 0);
     std::vector<uint32_t> sorted;

@@ -72,11 +72,23 @@ public:
     char** upper = nullptr;
     int sum_order = 1;  // vdb_sum_order
     uint64_t version = 0;  // bumped by every mutation; the device copy remembers the one it mirrors
+    // An index opened for streaming to the device (vdb_index_load_to_device): everything but the level-0 block
+    // (level0 == nullptr) is here; the block - rows [list | vector | label], all but a few percent of the file -
+    // is read chunk by chunk by the uploader from rows_path at rows_offset and never kept on the host.
+    bool rows_resident = true;
+    std::string rows_path;
+    long long rows_offset = 0;
+    void require_rows(const char* what) const {
+        if (!rows_resident)
+            throw std::runtime_error(std::string(what) + ": this index was loaded straight to the device and keeps no rows on the "
+                                     "host - load it with vdb_index_load to edit, inspect or save it");
+    }
 
     // layer0_lists_as_upper: layer 0 gets the capacity of an upper layer (maxM0 = M).  Only the device
     // builder uses it, for the HNSW over the elements of level >= l that IS layer l of a larger index.
     HostIndex(int metric, size_t dim, size_t capacity, size_t M, size_t efc, size_t seed, bool layer0_lists_as_upper = false);
-    HostIndex(const std::string& path, int metric, size_t dim, size_t capacity_hint);
+    // stream_rows: see rows_resident
+    HostIndex(const std::string& path, int metric, size_t dim, size_t capacity_hint, bool stream_rows = false);
     ~HostIndex();
     HostIndex(const HostIndex&) = delete;
     HostIndex& operator=(const HostIndex&) = delete;
@@ -134,7 +146,7 @@ private:
 
     bool layer0_as_upper_ = false;
     void init_layout();
-    void alloc_storage(size_t cap);
+    void alloc_storage(size_t cap, bool with_rows = true);
     void release();
     int draw_level();
     void insert(uint32_t id, const float* vec, int level, BuildScratch& sc);

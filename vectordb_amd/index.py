@@ -63,18 +63,23 @@ class HierarchicalNSW:
     """HierarchicalNSW<float> (hnsw_core.hpp:21)."""
 
     def __init__(self, space: _Space, capacity: int = 0, M: int = 16, ef_construction: int = 200,
-                 random_seed: int = 100, reuse_deleted: bool = False, *, location: str | None = None):
+                 random_seed: int = 100, reuse_deleted: bool = False, *, location: str | None = None,
+                 stream_to_device: int | None = None):
+        """``location``: the load constructor.  With ``stream_to_device`` = a device ordinal the file's level-0 block is
+        streamed to that GPU without a host copy (vdb_index_load_to_device): the index searches, but cannot be edited or saved."""
         if reuse_deleted:
             raise VdbError(_lib.VDB_ERR_UNSUPPORTED, "reuse_deleted is not implemented")
         self._l = _lib.lib()
         self.space = space
         self._h = C.c_void_p()
-        if location is not None:  # load ctor, hnsw_core.hpp:110-116
+        if location is not None and stream_to_device is not None:
+            check(self._l.vdb_index_load_to_device(C.byref(self._h), location.encode(), space.metric, space.dim, int(stream_to_device)))
+        elif location is not None:  # load ctor, hnsw_core.hpp:110-116
             check(self._l.vdb_index_load(C.byref(self._h), location.encode(), space.metric, space.dim, capacity))
         else:
             check(self._l.vdb_index_create(C.byref(self._h), space.metric, space.dim, capacity, M, ef_construction,
                                            random_seed))
-        self._device = None
+        self._device = stream_to_device if location is not None else None
 
     def __del__(self):
         h = getattr(self, "_h", None)
