@@ -221,3 +221,27 @@ def test_bruteforce_with_a_filter(orc, n, dim, metric, k, mod, keep):
     assert (found % mod == keep).all()
     one = b.SearchKNNCloserFirst(q[0], k, filter=lambda lab: lab % mod == keep)
     assert [lab for _, lab in one] == [int(v) for v in l[0] if v != np.uint64(2**64 - 1)]
+
+
+def test_mfma_bf16_duplicate_flood(orc):
+    """Thousands of base rows at exactly the k-th distance: every one of them passes the running threshold, the waves'
+    record lists of bf_gemm8_filter fill up (512 per wave and launch) and its in-place path and the buffers' overflow
+    handling run.  With ties the labels are not determined by the bf16 pass, the DISTANCES are: they must be the exact
+    top-k distances."""
+    rng = np.random.default_rng(9)
+    dim, n, k = 64, 40000, 10
+    v0 = rng.standard_normal(dim).astype(np.float32)
+    x = rng.standard_normal((n, dim)).astype(np.float32) * 3
+    dup = rng.permutation(n)[:30000]
+    x[dup] = v0
+    q = (v0 + 0.01 * rng.standard_normal((300, dim))).astype(np.float32)
+    b = vi.BruteforceSearch(vi.L2Space(dim), n)
+    b.add_items(x)
+    b.to_device(0)
+    r = oracle_bf(orc, x, None, vi.L2, q[:40], k)
+    d2, l2 = b.search_batch(q, k, precision=vi.BF_BF16_RERANK)
+    np.testing.assert_array_equal(d2[:40].view(np.uint32), r["dist"].view(np.uint32))
+    assert np.isin(l2, dup).all()
+    d0, l0 = b.search_batch(q[:40], k)    # the f32 path stays bit-exact, labels included
+    np.testing.assert_array_equal(l0, r["label"].astype(np.uint64))
+    np.testing.assert_array_equal(d0.view(np.uint32), r["dist"].view(np.uint32))

@@ -183,3 +183,34 @@ def test_streamed_load_equals_two_step_load(orc, tmp_path):
                  lambda: one.addPoint(x[0], 10**9)):
         with pytest.raises(vi.VdbError, match="loaded straight to the device"):
             call()
+
+
+@pytest.mark.gpu
+def test_c3_full_size(orc):
+    """configs[2] at full size (1M x 960 GIST-like, 10 000 queries, k = 10) on the HIP path: the f32 path equals the
+    oracle's brute force bit for bit on a sample of queries (the oracle needs seconds per query at this size), the
+    bf16 + re-rank path returns the same neighbours (recall reported, >= 0.999) with exact distances, both are
+    idempotent, and the result rows are sorted by (dist, label)."""
+    dim, n, nq, k = 960, 1_000_000, 10_000, 10
+    law = datasets.ClusteredLaw(dim, latent=64)
+    base = law.sample(n, seed=1)
+    q = law.sample(nq, seed=2)
+    b = vi.BruteforceSearch(vi.L2Space(dim), n)
+    b.add_items(base)
+    b.to_device(0)
+    d32, l32 = b.search_batch(q, k)
+    ob = orc.OracleBruteforce(orc.L2, dim, n, mode=orc.TREE64, o3=True)
+    ob.add(base)
+    r = ob.search(q[:24], k, n_threads=16)
+    np.testing.assert_array_equal(l32[:24], r["label"].astype(np.uint64))
+    np.testing.assert_array_equal(d32[:24].view(np.uint32), r["dist"].view(np.uint32))
+    d16, l16 = b.search_batch(q, k, precision=vi.BF_BF16_RERANK)
+    rec = datasets.recall_at_k(l16, l32)
+    print(f"C3 full size: bf16_rerank recall@10 vs exact = {rec:.5f}")
+    assert rec >= 0.999
+    same = l16 == l32
+    np.testing.assert_array_equal(d16[same].view(np.uint32), d32[same].view(np.uint32))   # exact distances after the re-rank
+    assert (np.diff(d32, axis=1) >= 0).all() and (np.diff(d16, axis=1) >= 0).all()
+    d32b, l32b = b.search_batch(q, k)
+    np.testing.assert_array_equal(l32b, l32)
+    np.testing.assert_array_equal(d32b.view(np.uint32), d32.view(np.uint32))
