@@ -923,6 +923,8 @@ __global__ __launch_bounds__(64) void bf_rerank(RerankArgs a) {
         const uint32_t row = live ? (uint32_t)ent[i] : 0u;
         const float* xr = a.raw + (size_t)row * a.vstride;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        // (one chunk of the row at a time; with four requested ahead the C3 re-rank took 0.71 ms instead of 0.47: the
+        // 10 000 waves already keep more random 3 840-B rows in flight than the memory side likes)
         for (uint32_t j = 0; j < nch; ++j) {
             const uint32_t e = 64 * j + 4 * t;
             f32x4 x = f32x4{0.f, 0.f, 0.f, 0.f};
