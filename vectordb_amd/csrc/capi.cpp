@@ -564,8 +564,7 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
     }
     work.bitmaps = (uint32_t*)s.bitmaps.p;
     work.bitmap_words = s.bitmap_words;
-    static const bool no_ghash = std::getenv("VDB_NO_GHASH") != nullptr;  // TEMP A/B
-    if (ef > 124 && !allow && !no_ghash) {
+    if (ef > 124 && !allow) {
         if (!s.ghash.p) s.ghash.alloc(((size_t)kGlobalHashBlocks << kGlobalHashBits) * 4);
         work.ghash = (uint32_t*)s.ghash.p;
     }
