@@ -525,7 +525,8 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
     }
     // The LDS visited set is sized for a typical search (hnsw_search.hip); what "typical" is depends on
     // the data.  Each launch reports how many queries outgrew it; when that was more than 2 % the
-    // next launches at this ef get a table twice the size (sticky, at most 2^14 entries).
+    // next launches at this ef get a table twice the size, four times when it was more than half
+    // of them (sticky, at most 2^14 entries).
     if (!s.report) {
         VDB_HIP(hipHostMalloc((void**)&s.report, 8, hipHostMallocMapped));
         s.report[0] = s.report[1] = 0;
@@ -542,7 +543,7 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
                 if (redone != 0) idx->spill_ef.insert(s.report_ef);
                 if ((uint64_t)redone * 50u > of) {
                     uint32_t& b = idx->hbits_bias[s.report_ef];
-                    if (b < 3) b += 1;
+                    b = std::min(3u, b + ((uint64_t)redone * 2u > of ? 2u : 1u));
                 }
             }
             s.report[0] = s.report[1] = 0;
@@ -806,7 +807,7 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
                         work.spill = (uint32_t*)sc->spill.p;
                         work.spill_tables = sc->spill_tables;
                     }
-                    if ((uint64_t)redone * 50u > of && work.hbits_bias < 3) work.hbits_bias += 1;
+                    if ((uint64_t)redone * 50u > of) work.hbits_bias = std::min(3u, work.hbits_bias + ((uint64_t)redone * 2u > of ? 2u : 1u));
                 }
                 sc->report[0] = sc->report[1] = 0;
                 sc->report_pending = false;

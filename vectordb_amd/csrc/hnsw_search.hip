@@ -550,6 +550,7 @@ __global__ __launch_bounds__(64, (R <= 2 && !FILT && VIS != 2) ? 4 : 2) void hns
                 // sequential admission in list order with the evolving bound, :339-349
                 uint64_t pend = ballot(dord < bound);
                 bool lost = false;  // lane 63: an unexpanded key at the bound's distance fell off the end
+                bool trim_due = false;
                 while (pend) {
                     const int r = __builtin_ctzll(pend);
                     pend &= pend - 1;
@@ -570,10 +571,16 @@ __global__ __launch_bounds__(64, (R <= 2 && !FILT && VIS != 2) ? 4 : 2) void hns
                             arr.insert(d, id << 1, lane, prev_hi, prev_lo);
                             bound = arr.hi_at(ef - 1);
                             lost |= lane == 63 && prev_hi != kEmptyWord && prev_hi == bound && (prev_lo & 1u) == 0u;
-                            arr.trim(ef, bound, lane);
+                            trim_due = true;
                         }
                         pend &= ballot(dord < bound);
                     }
+                }
+                // Entries behind index ef-1 whose distance is no longer the bound's are dropped once per chunk, not per
+                // insert: until then they sit behind the live ones (they are larger), fall off the end before them, and
+                // nothing between two pops looks at them.
+                if constexpr (!FILT) {
+                    if (trim_due) arr.trim(ef, bound, lane);
                 }
                 if (ballot(lost)) overflow = true;
             }
@@ -968,9 +975,11 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
     SearchArgs b = a;
     if (lds_small) {
         // The table gets the share of the CU's LDS that the kernel's register-limited residency leaves to a
-        // query: LDS, not registers, should never be what bounds the chains in flight, and a larger table
-        // than the power of two `hbits` asks for costs nothing then.  When hbits asks for more than that
-        // share (large ef, or raised by the caller after overflows) residency is given up for it.
+        // query: LDS, not registers, should never be what bounds the chains in flight (a 16 KB table at ef 100
+        // left 10 queries resident per CU where the registers allow 16: 1.27 ms per C2 batch against 0.92).
+        // Residency is given up for a larger table only when `hbits` asks for one, i.e. after launches at this ef
+        // in which more than 2 % of the queries outgrew the table (a 20M x 128 graph at ef 100 visits 2 000 nodes a
+        // query where C2 visits 900: sending most of a batch through the spill tables cost 5.9 ms against 2.6).
         static const uint32_t per_cu = [&] {  // blocks of this instantiation a CU holds by registers alone
             int n = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hnsw_search_kernel<NCH, GPB, R, 0, true, FILT>, 64, 1024) != hipSuccess || n <= 0)
@@ -1074,15 +1083,14 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
     a.nq = nq;
     a.k = k;
     a.ef = ef;
-    // Visited-set size.  The LDS it takes bounds the queries resident on a CU (160 KiB / table), so
-    // it is sized for what a search typically visits (about ef * maxM0 / 4 nodes on the C2 data,
-    // i.e. half of `need` at the 75 % fill limit), not for the worst case ef * maxM0: a query that
-    // outgrows it is re-run exactly by the large configuration.
-    // (measured on C2, 10 000 queries: ef 100 1.25 ms at 2^12 against 1.59 at 2^11 and 2.33 at 2^13;
-    //  ef 256 3.98 ms at 2^12 against 6.57 at 2^13 and 11.4 at 2^14)
-    uint32_t need = (uint32_t)((uint64_t)ef * g.l0stride / 2u), hb = ef <= 64 ? 11 : 12;
-    while ((1u << hb) < need && hb < 14) ++hb;
-    hb += work.hbits_bias;  // raised by the caller when earlier launches at this ef overflowed often
+    // Visited-set size.  The LDS table is what the kernel's residency leaves to a query (launch_cfg: 10-13 KB, 1 900 to
+    // 2 500 nodes at the 75 % fill limit), whatever ef: a search that visits more carries on in a spill table, or is
+    // re-run exactly by the large configuration.  `hbits` starts at 2^11 entries and is raised by the caller when more
+    // than 2 % of a launch at this ef outgrew the table: 2^12 and 2^13 entries then take LDS from the residency, and from
+    // 2^13 on the searches with four or more key registers move their visited set to HBM altogether (launch_cfg).
+    // (round 1 sized the table by ef - 2^12 from ef 65 on, more by ef * maxM0 / 2: ef 100 then ran with 10 queries per CU)
+    uint32_t hb = 11;
+    hb += work.hbits_bias;
     if (hb > 14) hb = 14;
     a.hbits = hb;
     a.allow = d_allow;
