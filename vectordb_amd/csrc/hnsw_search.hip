@@ -193,6 +193,7 @@ struct KeyArray {
             lo[r] = (uint32_t)nv;
         }
     }
+    __device__ __forceinline__ uint64_t key(int r) const { return ((uint64_t)hi[r] << 32) | lo[r]; }
     // Entries at index >= ef survive only while their distance equals the bound.
     __device__ __forceinline__ void trim(uint32_t ef, uint32_t bound_hi, int lane) {
 #pragma unroll
@@ -324,6 +325,8 @@ struct SearchArgs {
     const float* queries;  // [nq][dim]
     uint32_t nq, k, ef, hbits;
     uint32_t lds_entries;  // LdsVisited::size of this launch
+    uint32_t stage_off;    // word offset in the block's LDS of the 64 R keys that KeyArray::merge stages (behind the LDS
+                           // table; 0 in the configurations without one, where it shares the epilogue's space)
     float* out_dist;       // [nq][k]
     uint64_t* out_label;   // [nq][k]
     uint32_t* out_stats;   // nullable [nq][4]
@@ -551,6 +554,81 @@ __global__ __launch_bounds__(64, (R <= 2 && !FILT && VIS != 2) ? 4 : 2) void hns
                 uint64_t pend = ballot(dord < bound);
                 bool lost = false;  // lane 63: an unexpanded key at the bound's distance fell off the end
                 bool trim_due = false;
+                if constexpr (!FILT) {
+                    // Two or more neighbours below the bound: one merge instead of one wave-wide shift each.  Every key
+                    // learns its place in the merged order by counting (an array entry moves back by the number of new
+                    // keys below it, a new key stands behind the array entries and the new keys below it), the key
+                    // that lands on index ef-1 gives the bound that sequential admission would end with, and the keys
+                    // move through LDS.  The two orders of work end in the same array unless a new key TIES with the
+                    // final bound and is not alone at that distance (:339 admits on strict <, so which of the equal
+                    // keys stay depends on the list order): then nothing has been touched yet and the sequential loop
+                    // below runs as before.  (Otherwise: a new key beyond the final bound is either never admitted or
+                    // admitted, pushed behind index ef-1 and trimmed; one at or below it is admitted in both.)
+                    if (pend & (pend - 1)) {
+                        const bool in_p = (pend >> lane) & 1u;
+                        const uint32_t my_lo = ids_part << 1;
+                        const uint64_t mk = ((uint64_t)dord << 32) | my_lo;
+                        uint32_t sh[R];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) sh[r] = 0;
+                        uint32_t mypos = 0;
+                        for (uint64_t it = pend; it; it &= it - 1) {
+                            const int c = __builtin_ctzll(it);
+                            const uint64_t ck = ((uint64_t)readlane(dord, c) << 32) | readlane(my_lo, c);
+                            uint32_t below = 0;
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                const bool lt = arr.key(r) < ck;  // (keys are distinct: a new key is an unvisited node)
+                                sh[r] += lt ? 0u : 1u;
+                                below += (uint32_t)__builtin_popcountll(ballot(lt));
+                            }
+                            mypos += lane == c ? below : (mk > ck ? 1u : 0u);
+                        }
+                        uint32_t nbound = kEmptyWord;  // an EMPTY entry on index ef-1: the result set is not full yet
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const uint64_t h = ballot((uint32_t)(r * 64 + lane) + sh[r] == ef - 1u);
+                            if (h) nbound = readlane(arr.hi[r], __builtin_ctzll(h));
+                        }
+                        {
+                            const uint64_t h = ballot(in_p && mypos == ef - 1u);
+                            if (h) nbound = readlane(dord, __builtin_ctzll(h));
+                        }
+                        bool tie = false;
+                        const uint64_t at = ballot(in_p && dord == nbound);
+                        if (at) {
+                            uint32_t cnt = (uint32_t)__builtin_popcountll(at);
+#pragma unroll
+                            for (int r = 0; r < R; ++r) cnt += (uint32_t)__builtin_popcountll(ballot(arr.hi[r] == nbound));
+                            tie = cnt >= 2;
+                        }
+                        if (!tie) {
+                            uint64_t* st = reinterpret_cast<uint64_t*>(lds + a.stage_off);
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                const uint32_t pos = (uint32_t)(r * 64 + lane) + sh[r];
+                                if (pos < 64u * R) st[pos] = arr.key(r);
+                                else lost |= arr.hi[r] != kEmptyWord && arr.hi[r] == nbound && (arr.lo[r] & 1u) == 0u;
+                            }
+                            if (in_p && mypos < 64u * R) st[mypos] = mk;  // (one beyond the end is beyond the bound: ties went the other way)
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                const uint64_t v = st[r * 64 + lane];
+                                arr.hi[r] = (uint32_t)(v >> 32);
+                                arr.lo[r] = (uint32_t)v;
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                            __builtin_amdgcn_wave_barrier();
+                            bound = nbound;
+                            trim_due = true;
+                            pend = 0;
+                        }
+                    }
+                }
                 while (pend) {
                     const int r = __builtin_ctzll(pend);
                     pend &= pend - 1;
@@ -582,7 +660,7 @@ __global__ __launch_bounds__(64, (R <= 2 && !FILT && VIS != 2) ? 4 : 2) void hns
                 if constexpr (!FILT) {
                     if (trim_due) arr.trim(ef, bound, lane);
                 }
-                if (ballot(lost)) overflow = true;
+                if (ballot(lost)) overflow = true;  // (any lane: the merge loses keys from every lane that moves past the end)
             }
             if (overflow) break;
         }
@@ -989,7 +1067,10 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
         size_t share = ((size_t)160 * 1024 / per_cu) / 1024 * 1024;
         if (lds_small < share) lds_small = share;
         if (lds_small > (size_t)64 * 1024) lds_small = (size_t)64 * 1024;
-        b.lds_entries = (uint32_t)(lds_small / 4);
+        // (behind the table: the 64 R keys of KeyArray::merge, in whole KB as the table's size is)
+        const size_t stage_bytes = FILT ? 0 : ((size_t)64 * R * 8 + 1023) / 1024 * 1024;
+        b.lds_entries = (uint32_t)((lds_small - stage_bytes) / 4);
+        b.stage_off = b.lds_entries;
         // the spill variant costs the searches that never spill 1-5 % (a uniform branch per hop in the
         // hash probe): the caller passes the tables only when earlier launches at this ef needed them
         if (a.spill) {
@@ -1077,7 +1158,7 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
         if (err) *err = "hnsw_search: the graph has elements but no entry point";
         return 2;
     }
-    SearchArgs a;
+    SearchArgs a{};
     a.g = g;
     a.queries = d_queries;
     a.nq = nq;
