@@ -86,8 +86,9 @@ def test_small_and_empty_indexes(orc):
 @pytest.mark.parametrize("nq,spill", [(32, "1"), (32, "0"), (700, "1"), (32, None)])
 def test_visited_overflow_is_exact(orc, monkeypatch, nq, spill):
     """ef=256 on a graph of 6000 nodes visits most of it: every query fills its LDS table.  With spill
-    tables ("1") it carries on in a second-level table in HBM; without ("0", or once the 512 tables of a
-    launch are taken: nq=700) it is re-run by the large configuration (bitmap).  Unset, the library
+    tables ("1") it carries on in a second-level table in HBM (nq=700: more spilling queries than the
+    pool's 704 tables can be short of when they are resident at once); without ("0") it is re-run by the
+    large configuration (bitmap).  Unset, the library
     hands out the tables from the second launch on.  Same answers every way."""
     if spill is None:
         monkeypatch.delenv("VDB_SPILL", raising=False)
@@ -105,10 +106,10 @@ def test_visited_overflow_is_exact(orc, monkeypatch, nq, spill):
 
 
 def test_spill_pool_grows_with_the_batch(orc, monkeypatch):
-    """The pool holds one spill table per 16 queries of the largest batch (512 to 4096): a 20 000-query
-    batch after a small one re-allocates it, 1 250 queries carry on in spill tables and the rest are
-    re-run by the large configuration.  Both ways are exact, so the answers equal those of a run without
-    spill tables, and the oracle's on a sample."""
+    """The pool holds one spill table per query of the largest batch (512 to 4096) and a table goes back
+    to it when its query ends: a 20 000-query batch after a small one re-allocates the pool, and its
+    20 000 spilling queries share the 4 096 tables (each is taken about five times in the launch).  The
+    answers equal those of a run without spill tables (bitmap re-runs), and the oracle's on a sample."""
     x = datasets.uniform(6000, 16, 11)
     q = datasets.uniform(20000, 16, 31)
     h, o = build_pair(orc, x, vi.L2, 16, 64)

@@ -451,7 +451,7 @@ SearchScratch& scratch_for(vdb_index* idx, hipStream_t stream, size_t nq) {
         s.redo.alloc((nq + kRedoHeader) * 4 * 2);
         s.redo_cap = (nq + kRedoHeader) * 2 - kRedoHeader;
     }
-    const uint32_t tables = (uint32_t)std::min<size_t>(std::max<size_t>(nq / 16, kSpillTablesMin), kSpillTablesMax);
+    const uint32_t tables = (uint32_t)std::min<size_t>(std::max<size_t>((nq + 31) / 32 * 32, kSpillTablesMin), kSpillTablesMax);
     if (s.spill_tables < tables) {
         if (s.spill.p) VDB_HIP(hipStreamSynchronize(stream));
         s.spill.alloc(((size_t)tables << kSpillBits) * 4);
@@ -524,9 +524,8 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
         allow = (const uint32_t*)s.allow.p;
     }
     // The LDS visited set is sized for a typical search (hnsw_search.hip); what "typical" is depends on
-    // the data.  Each launch reports how many queries outgrew it; when that was more than 2 % the
-    // next launches at this ef get a table twice the size, four times when it was more than half
-    // of them (sticky, at most 2^14 entries).
+    // the data.  Each launch reports how many queries outgrew it, and next_hbits_bias (launch.hpp)
+    // decides whether the next launches at this ef get a table twice the size (sticky, at most 2^14 entries).
     if (!s.report) {
         VDB_HIP(hipHostMalloc((void**)&s.report, 8, hipHostMallocMapped));
         s.report[0] = s.report[1] = 0;
@@ -541,10 +540,8 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
             const uint32_t redone = s.report[0], of = s.report[1];
             if (of != 0 && s.report_ef != 0) {
                 if (redone != 0) idx->spill_ef.insert(s.report_ef);
-                if ((uint64_t)redone * 50u > of) {
-                    uint32_t& b = idx->hbits_bias[s.report_ef];
-                    b = std::min(3u, b + ((uint64_t)redone * 2u > of ? 2u : 1u));
-                }
+                uint32_t& b = idx->hbits_bias[s.report_ef];
+                b = next_hbits_bias(b, redone, of);
             }
             s.report[0] = s.report[1] = 0;
             s.report_pending = false;
@@ -807,7 +804,7 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
                         work.spill = (uint32_t*)sc->spill.p;
                         work.spill_tables = sc->spill_tables;
                     }
-                    if ((uint64_t)redone * 50u > of) work.hbits_bias = std::min(3u, work.hbits_bias + ((uint64_t)redone * 2u > of ? 2u : 1u));
+                    work.hbits_bias = next_hbits_bias(work.hbits_bias, redone, of);
                 }
                 sc->report[0] = sc->report[1] = 0;
                 sc->report_pending = false;

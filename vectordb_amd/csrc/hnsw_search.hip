@@ -53,7 +53,7 @@ using namespace dev;
 template <bool SPILL>
 struct LdsVisited {
     uint32_t* tab;
-    uint32_t size;  // entries, a multiple of 256 (not a power of two: the launcher gives a query the share of the
+    uint32_t size;  // entries, a multiple of 4 (not a power of two: the launcher gives a query the share of the
                     // CU's LDS that its residency leaves, see launch_cfg)
     // Second level, in HBM, taken when the LDS table reaches its fill limit (take_spill): the LDS
     // table is then frozen (looked up, never inserted into) and new ids go to the spill table, so the
@@ -61,7 +61,6 @@ struct LdsVisited {
     uint32_t* spill;
     __device__ __forceinline__ void clear(int lane) {
         for (uint32_t i = lane * 4; i < size; i += 256) *reinterpret_cast<uint4*>(tab + i) = uint4{~0u, ~0u, ~0u, ~0u};
-        spill = nullptr;
     }
     // true when `id` was not in the set (and inserts it)
     __device__ __forceinline__ bool test_and_set(uint32_t id) {
@@ -90,20 +89,48 @@ struct LdsVisited {
         return old == kEmptyWord;
     }
     __device__ __forceinline__ uint32_t limit() const { return size - (size >> 2); }  // 75 % fill
-    // Called by the whole wave when the next hop could pass the limit; `taken` = the launch's counter of
-    // spill tables.  Returns the new limit, or 0 when there is no table to take (none configured,
-    // all taken, or this query has one already).
-    __device__ __forceinline__ uint32_t take_spill(uint32_t* pool, uint32_t tables, uint32_t* taken, int lane) {
+    // Called by the whole wave when the next hop could pass the limit; `map` = the launch's bitmap of tables in use
+    // (`tables` bits, a multiple of 32), `taken` = its counter of queries that took one.  Returns the new limit, or 0
+    // when there is no table to take (none configured, all in use, or this query has one already).  The table goes
+    // back with release_spill when the query ends: the tables a launch needs are the queries resident at once, not
+    // the queries that spill (round 1 handed each table out once: a batch whose every query spilled - 10 000 queries
+    // at ef 100 on a 20 M-row graph, 625 tables - ran 30 ms instead of 3, nine tenths of it re-run by the large
+    // configuration).
+    __device__ __forceinline__ uint32_t take_spill(uint32_t* pool, uint32_t tables, uint32_t* map, uint32_t* taken, int lane) {
         if (!SPILL || pool == nullptr || spill != nullptr) return 0u;
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(taken, 1u);
+        uint32_t t = kEmptyWord;
+        if (lane == 0) {
+            const uint32_t words = tables >> 5;
+            uint32_t w = __umulhi(blockIdx.x * 0x9E3779B1u, words);  // (spread the first probes over the words)
+            for (uint32_t i = 0; i < words && t == kEmptyWord; ++i) {
+                uint32_t cur = __hip_atomic_load(&map[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (cur != 0xFFFFFFFFu) {
+                    const uint32_t bit = 1u << __builtin_ctz(~cur);
+                    cur = atomicOr(&map[w], bit);
+                    if ((cur & bit) == 0u) {
+                        t = (w << 5) + (uint32_t)__builtin_ctz(bit);
+                        break;
+                    }
+                }
+                w = w + 1u == words ? 0u : w + 1u;
+            }
+            if (t != kEmptyWord) atomicAdd(taken, 1u);
+        }
         t = readlane(t, 0);
-        if (t >= tables) return 0u;
+        if (t == kEmptyWord) return 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // behind the last owner's release
         spill = pool + ((size_t)t << kSpillBits);
         for (uint32_t i = lane * 4; i < (1u << kSpillBits); i += 256)
             *reinterpret_cast<uint4*>(spill + i) = uint4{~0u, ~0u, ~0u, ~0u};
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the stores reach L2 ahead of the other lanes' atomics
         return limit() + ((3u << kSpillBits) >> 2);
+    }
+    __device__ __forceinline__ void release_spill(uint32_t* pool, uint32_t* map, int lane) {
+        if (!SPILL || spill == nullptr) return;
+        const uint32_t t = (uint32_t)((size_t)(spill - pool) >> kSpillBits);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this query's probes are done before the table changes hands
+        if (lane == 0) atomicAnd(&map[t >> 5], ~(1u << (t & 31u)));
+        spill = nullptr;
     }
 };
 
@@ -356,8 +383,16 @@ struct SearchArgs {
 // (exact unless the key array itself overflows, which is reported per query: found = UINT32_MAX),
 // 3 = 0 with a second-level table in HBM for the queries that fill the LDS one (LdsVisited).
 // Registers: R <= 2 (ef <= 124, bare) fits 128 VGPRs = four waves per SIMD; left alone the R == 2 body took 129.
+// Four waves per SIMD (128 registers) where the body fits them without scratch: one or two key registers, and the larger
+// arrays with 8 row chunks of 16 B per lane in flight instead of 16 (launch_r); up to dim 256 (R = 8 at dim 129-256 is 6
+// registers short; from dim 257 on the query and one row in flight alone take 64-128 registers: bounding those to 128
+// put 13-130 registers into scratch, which round 1 did for R <= 2).
+constexpr bool four_waves(int nch, int gpb, int r, int vis, bool filt) {
+    return !filt && vis != 2 && nch <= 4 && (r <= 2 || (nch * gpb <= 8 && (nch <= 2 || r <= 5)));
+}
+
 template <int NCH, int GPB, int R, int VIS, bool IS_L2, bool FILT>
-__global__ __launch_bounds__(64, (R <= 2 && !FILT && VIS != 2) ? 4 : 2) void hnsw_search_kernel(SearchArgs a) {
+__global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) void hnsw_search_kernel(SearchArgs a) {
     constexpr int S = FILT ? 2 : 1;
     constexpr bool LARGE = VIS == 2;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -374,12 +409,13 @@ __global__ __launch_bounds__(64, (R <= 2 && !FILT && VIS != 2) ? 4 : 2) void hns
     } else {
         vis.tab = lds;
         vis.size = a.lds_entries;
+        vis.spill = nullptr;
     }
 
     const uint32_t n_work = LARGE ? a.redo[0] : a.nq;
     if constexpr (LARGE) {  // tells the host how the visited-set size chosen for this launch fared
         if (blockIdx.x == 0 && lane == 0 && a.report) {
-            const uint32_t spilled = a.redo[2] < a.spill_tables ? a.redo[2] : a.spill_tables;
+            const uint32_t spilled = a.redo[2];
             a.report[0] = n_work + spilled;  // the queries that outgrew the LDS table, whichever way they went on
             a.report[1] = a.nq;
         }
@@ -506,7 +542,7 @@ __global__ __launch_bounds__(64, (R <= 2 && !FILT && VIS != 2) ? 4 : 2) void hns
             hops0 += 1;
             if (nvis + g.l0stride > vis_limit) {
                 uint32_t more = 0;
-                if constexpr (VIS == 3) more = vis.take_spill(a.spill, a.spill_tables, a.redo + 2, lane);
+                if constexpr (VIS == 3) more = vis.take_spill(a.spill, a.spill_tables, a.redo + kRedoSpillMap, a.redo + 2, lane);
                 if (more == 0) {
                     overflow = true;
                     break;
@@ -664,6 +700,7 @@ __global__ __launch_bounds__(64, (R <= 2 && !FILT && VIS != 2) ? 4 : 2) void hns
             }
             if (overflow) break;
         }
+        if constexpr (VIS == 3) vis.release_spill(a.spill, a.redo + kRedoSpillMap, lane);
 
         if (overflow) {
             if constexpr (!LARGE) {
@@ -1028,8 +1065,11 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
     const size_t epilogue_bytes = (size_t)64 * R * 12;
     size_t lds_small = (size_t)4 << a.hbits;
     if (lds_small < epilogue_bytes) lds_small = epilogue_bytes;
-    if constexpr (R >= 4 && !FILT) {
-        // an LDS table of 32 KB or more would leave five or fewer queries resident per CU
+    if constexpr (R >= 5 && !FILT) {
+        // Searches that visit far more than a 16 KB LDS table holds: the whole visited set in HBM, one table per resident
+        // wave.  From ef 253 on only: below, the LDS table with a spill table behind it is as fast or faster now that a
+        // launch cannot run out of spill tables (20 M x 128, 10 000 queries, LDS + spill against this: ef 200 6.4 / 7.0 ms,
+        // ef 300 9.5 / 9.6, ef 400 14.2 / 12.3, ef 508 23.2 / 15.7).
         if (a.hbits >= 13 && a.ghash) {
             // persistent blocks: as many as are resident at once, each with its own table
             static const uint32_t resident = [&] {
@@ -1062,13 +1102,16 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
             int n = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hnsw_search_kernel<NCH, GPB, R, 0, true, FILT>, 64, 1024) != hipSuccess || n <= 0)
                 return 8u;
-            return (uint32_t)n;
+            return (uint32_t)(n > 16 ? 16 : n);  // (a body under 100 registers could have 20: an 8 KB table is too small)
         }();
         size_t share = ((size_t)160 * 1024 / per_cu) / 1024 * 1024;
         if (lds_small < share) lds_small = share;
+        // with spill tables to carry on in, never more than 16 KB (10 queries per CU): 32 KB for everyone cost more than
+        // the spilling of the long searches did (3.1 against 2.2 ms at ef 100 on the 20 M-row graph)
+        if (a.spill && lds_small > (size_t)16 * 1024) lds_small = (size_t)16 * 1024;
         if (lds_small > (size_t)64 * 1024) lds_small = (size_t)64 * 1024;
-        // (behind the table: the 64 R keys of KeyArray::merge, in whole KB as the table's size is)
-        const size_t stage_bytes = FILT ? 0 : ((size_t)64 * R * 8 + 1023) / 1024 * 1024;
+        // (behind the table: the 64 R keys of KeyArray::merge)
+        const size_t stage_bytes = FILT ? 0 : (size_t)64 * R * 8;
         b.lds_entries = (uint32_t)((lds_small - stage_bytes) / 4);
         b.stage_off = b.lds_entries;
         // the spill variant costs the searches that never spill 1-5 % (a uniform branch per hop in the
@@ -1125,9 +1168,14 @@ int launch_r(const SearchArgs& a, hipStream_t stream, std::string* err) {
     // at ef 62 and at ef 65)
     if (a.ef <= 60) return launch_cfg<NCH, GPB, 1, 2, false>(a, stream, err);
     if (a.ef <= 124) return launch_cfg<NCH, GPB, 2, 4, false>(a, stream, err);
-    if (a.ef <= 252) return launch_cfg<NCH, GPB, 4, 8, false>(a, stream, err);
-    if (a.ef <= 316) return launch_cfg<NCH, GPB, 5, 10, false>(a, stream, err);
-    return launch_cfg<NCH, GPB, 8, 16, false>(a, stream, err);
+    // From three key registers on, half the rows in flight per pass of score_nodes: at these ef a hop brings 4-8 unvisited
+    // neighbours, not 16-32, and the 32 registers that frees take the body from 134-150 to 92-127: four waves per SIMD
+    // instead of three (C2, 100 000 queries: ef 128 10.8 -> 8.5 ms, ef 200 15.9 -> 12.6, ef 252 19.6 -> 14.9).
+    constexpr int GH = GPB >= 2 ? GPB / 2 : GPB;
+    if (a.ef <= 188) return launch_cfg<NCH, GH, 3, 6, false>(a, stream, err);
+    if (a.ef <= 252) return launch_cfg<NCH, GH, 4, 8, false>(a, stream, err);
+    if (a.ef <= 316) return launch_cfg<NCH, GH, 5, 10, false>(a, stream, err);
+    return launch_cfg<NCH, GH, 8, 16, false>(a, stream, err);
 }
 
 }  // namespace
@@ -1167,8 +1215,8 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
     // Visited-set size.  The LDS table is what the kernel's residency leaves to a query (launch_cfg: 10-13 KB, 1 900 to
     // 2 500 nodes at the 75 % fill limit), whatever ef: a search that visits more carries on in a spill table, or is
     // re-run exactly by the large configuration.  `hbits` starts at 2^11 entries and is raised by the caller when more
-    // than 2 % of a launch at this ef outgrew the table: 2^12 and 2^13 entries then take LDS from the residency, and from
-    // 2^13 on the searches with four or more key registers move their visited set to HBM altogether (launch_cfg).
+    // than 2 % of a launch at this ef outgrew the table (next_hbits_bias): 2^12 entries take LDS from the residency, and
+    // from 2^13 on the searches with five or more key registers move their visited set to HBM altogether (launch_cfg).
     // (round 1 sized the table by ef - 2^12 from ef 65 on, more by ef * maxM0 / 2: ef 100 then ran with 10 queries per CU)
     uint32_t hb = 11;
     hb += work.hbits_bias;

@@ -17,9 +17,11 @@ constexpr uint32_t kGlobalHashBits = 15;     // 32 768 entries (128 KB) per resi
 constexpr uint32_t kGlobalHashBlocks = 4096;  // resident waves of the global-hash configuration (512 MB of tables)
 constexpr uint32_t kLargeBlocks = 128;     // resident waves of the large configuration (one bitmap each)
 constexpr uint32_t kSpillBits = 14;        // 16 384 entries (64 KB) per spill table: 12 288 more visited nodes
-constexpr uint32_t kSpillTablesMin = 512;  // spill tables per launch: nq / 16 within [512, 4096] (32-256 MB); a query that
-constexpr uint32_t kSpillTablesMax = 4096; // finds none left is re-run by the large configuration
-constexpr uint32_t kRedoHeader = 4;        // words ahead of the re-run list
+constexpr uint32_t kSpillTablesMin = 512;  // spill tables per launch: nq within [512, 4096] (32-256 MB).  A table goes back when its
+constexpr uint32_t kSpillTablesMax = 4096; // query ends, and a GPU holds at most 4096 of these searches at once (16 per CU by
+                                           // their LDS): with nq >= 4096 a query always finds one
+constexpr uint32_t kRedoSpillMap = 4;      // word offset in the work list's header of the bitmap of spill tables in use
+constexpr uint32_t kRedoHeader = kRedoSpillMap + kSpillTablesMax / 32;  // words ahead of the re-run list
 
 // The no-allocation entry point (vdb_search_batch_device_noalloc): limits and the layout of its static
 // scratch (noalloc_scratch.hip): [work list: kRedoHeader + kNoAllocMaxQueries words | pad to 256 B |
@@ -32,13 +34,25 @@ constexpr size_t kNoAllocScratchBytes = kNoAllocBitmapOffset + (size_t)kNoAllocL
 // Address of that scratch on `device` (which must be current); asked from the runtime once per device.
 int noalloc_scratch(int device, void** out, std::string* err);
 
+// The caller's rule for HnswSearchWork::hbits_bias, from a launch's report (`outgrew` of `nq` queries filled their LDS
+// table and went on in a spill table or in the large configuration).  The first step, 2^11 -> 2^12 entries, costs a
+// third of the residency and is taken when more than 2 % outgrew the table; the later ones halve it again (or move
+// the visited set to HBM, hnsw_search.hip) and are taken only when more than a quarter still do - the rest is what
+// the spill tables are for (20 M x 128, ef 100, 10 000 queries: 2.2 ms at 2^12 with the long searches spilling, 3.1 ms
+// at 2^13 with none).
+inline uint32_t next_hbits_bias(uint32_t bias, uint32_t outgrew, uint32_t nq) {
+    if (bias == 0) return (uint64_t)outgrew * 50u > nq ? 1u : 0u;
+    return (uint64_t)outgrew * 4u > nq && bias < 3u ? bias + 1u : bias;
+}
+
 struct HnswSearchWork {
     uint32_t* ghash = nullptr;    // nullable: [kGlobalHashBlocks << kGlobalHashBits] u32, visited tables in HBM (large ef)
     uint32_t* report = nullptr;   // nullable, host-mapped [2]: {queries re-run by the large configuration, nq} of this launch
     uint32_t hbits_bias = 0;      // added to log2 of the visited-set size the launcher picks
     uint32_t* redo = nullptr;     // [kRedoHeader + nq] u32; the header ([0] re-run count, [1] unanswerable filtered queries,
-                                  // [2] spill tables taken, [3] unused) is zeroed by the launcher
-    uint32_t spill_tables = 0;
+                                  // [2] spill tables taken, [3] queries beyond heap_cap, [kRedoSpillMap..] spill tables in
+                                  // use) is zeroed by the launcher
+    uint32_t spill_tables = 0;    // a multiple of 32, at most kSpillTablesMax
     uint32_t* spill = nullptr;    // nullable: [spill_tables << kSpillBits] u32, second-level visited tables in HBM for the
                                   // queries that fill their LDS table (any contents: a table is cleared when taken)
     uint32_t* bitmaps = nullptr;  // [large_blocks][bitmap_words]
