@@ -11,7 +11,9 @@ os.makedirs(out, exist_ok=True)
 newest = lambda pat: max(glob.glob(os.path.join(ROOT, "gpurun_out", pat)), key=os.path.getmtime)
 
 shutil.copy(newest("c2prof/*/*kernel_stats.csv"), os.path.join(out, "hnsw_c2_kernel_stats.csv"))
-shutil.copy(newest("c3prof/*/*kernel_stats.csv"), os.path.join(out, "bf_c3_kernel_stats.csv"))
+have = lambda pat: bool(glob.glob(os.path.join(ROOT, "gpurun_out", pat)))
+if have("c3prof/*/*kernel_stats.csv"):
+    shutil.copy(newest("c3prof/*/*kernel_stats.csv"), os.path.join(out, "bf_c3_kernel_stats.csv"))
 
 # FETCH_SIZE of the traversal at the headline configuration (ef = 32 -> the R = 1 instantiation)
 rows = [r for r in csv.DictReader(open(newest("c2pmc/*/*counter_collection.csv")))
@@ -25,6 +27,10 @@ json.dump({"kernel": "hnsw_search_kernel<2, 8, 1, 0, true, false> (NCH=2, GPB=8,
                    "dispatches at ef=32 (10000 queries x 64 lanes)",
            "command": "tools/prof_c2.sh: rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1"},
           open(os.path.join(out, "hnsw_c2_pmc_fetch.json"), "w"), indent=1)
+
+print(open(os.path.join(out, "hnsw_c2_pmc_fetch.json")).read())
+if not have(f"pmc_gemm_{tag}_sq/*/*counter_collection.csv"):
+    sys.exit(0)  # (only the C2 passes were re-run)
 
 # SQ / LDS counters of the bf16 GEMM, summed over the launches of one 400 000-row step
 res = {}
@@ -50,4 +56,3 @@ json.dump({"kernel": "bf_gemm8_filter<false, 0> (bf16 ping-pong loop), all slab 
            "command": f"tools/pmc_gemm.sh {tag}"},
           open(os.path.join(out, "bf_c3_pmc_gemm.json"), "w"), indent=1)
 print(open(os.path.join(out, "bf_c3_pmc_gemm.json")).read()[:1500])
-print(open(os.path.join(out, "hnsw_c2_pmc_fetch.json")).read())

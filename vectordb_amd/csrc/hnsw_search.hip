@@ -37,6 +37,7 @@
 #include <string>
 #include <type_traits>
 
+#include <cstdlib>
 #include "device_index.hpp"
 #include "launch.hpp"
 #include "traversal_common.hpp"
@@ -1220,6 +1221,7 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
     // (round 1 sized the table by ef - 2^12 from ef 65 on, more by ef * maxM0 / 2: ef 100 then ran with 10 queries per CU)
     uint32_t hb = 11;
     hb += work.hbits_bias;
+    if (const char* e = std::getenv("VDB_HB")) hb = (uint32_t)std::atoi(e);  // TEMP experiment
     if (hb > 14) hb = 14;
     a.hbits = hb;
     a.allow = d_allow;
