@@ -37,7 +37,6 @@
 #include <string>
 #include <type_traits>
 
-#include <cstdlib>
 #include "device_index.hpp"
 #include "launch.hpp"
 #include "traversal_common.hpp"
@@ -56,6 +55,9 @@ struct LdsVisited {
     uint32_t* tab;
     uint32_t size;  // entries, a multiple of 4 (not a power of two: the launcher gives a query the share of the
                     // CU's LDS that its residency leaves, see launch_cfg)
+    uint32_t mod;   // the largest prime <= size: the slots in use.  Double hashing (any step is coprime to a prime): at the
+                    // 75 % fill at which a table is frozen a lookup of an id that is not there walks 4 slots on average,
+                    // where linear probing walks 8.5 - and every probe of a spilled search is such a lookup
     // Second level, in HBM, taken when the LDS table reaches its fill limit (take_spill): the LDS
     // table is then frozen (looked up, never inserted into) and new ids go to the spill table, so the
     // set stays exact and the search carries on instead of starting again in the large configuration.
@@ -65,18 +67,21 @@ struct LdsVisited {
     }
     // true when `id` was not in the set (and inserts it)
     __device__ __forceinline__ bool test_and_set(uint32_t id) {
-        uint32_t s = __umulhi(id * 0x9E3779B1u, size);  // multiplicative hash onto [0, size)
+        uint32_t s = __umulhi(id * 0x9E3779B1u, mod);  // multiplicative hash onto [0, mod)
+        const uint32_t step = 1u + __umulhi(id * 0x85EBCA6Bu, mod - 1u);  // in [1, mod)
         if (!SPILL || spill == nullptr) {  // (wave-uniform)
             uint32_t old = atomicCAS(&tab[s], kEmptyWord, id);  // almost always decides
             while (old != kEmptyWord && old != id) {
-                s = s + 1u == size ? 0u : s + 1u;
+                s += step;
+                if (s >= mod) s -= mod;
                 old = atomicCAS(&tab[s], kEmptyWord, id);
             }
             return old == kEmptyWord;
         }
         uint32_t v = tab[s];  // frozen at 75 % fill or less: the probe ends
         while (v != kEmptyWord && v != id) {
-            s = s + 1u == size ? 0u : s + 1u;
+            s += step;
+            if (s >= mod) s -= mod;
             v = tab[s];
         }
         if (v == id) return false;
@@ -89,7 +94,7 @@ struct LdsVisited {
         }
         return old == kEmptyWord;
     }
-    __device__ __forceinline__ uint32_t limit() const { return size - (size >> 2); }  // 75 % fill
+    __device__ __forceinline__ uint32_t limit() const { return mod - (mod >> 2); }  // 75 % fill
     // Called by the whole wave when the next hop could pass the limit; `map` = the launch's bitmap of tables in use
     // (`tables` bits, a multiple of 32), `taken` = its counter of queries that took one.  Returns the new limit, or 0
     // when there is no table to take (none configured, all in use, or this query has one already).  The table goes
@@ -353,6 +358,7 @@ struct SearchArgs {
     const float* queries;  // [nq][dim]
     uint32_t nq, k, ef, hbits;
     uint32_t lds_entries;  // LdsVisited::size of this launch
+    uint32_t lds_mod;      // LdsVisited::mod
     uint32_t stage_off;    // word offset in the block's LDS of the 64 R keys that KeyArray::merge stages (behind the LDS
                            // table; 0 in the configurations without one, where it shares the epilogue's space)
     float* out_dist;       // [nq][k]
@@ -410,6 +416,7 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
     } else {
         vis.tab = lds;
         vis.size = a.lds_entries;
+        vis.mod = a.lds_mod;
         vis.spill = nullptr;
     }
 
@@ -1066,11 +1073,12 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
     const size_t epilogue_bytes = (size_t)64 * R * 12;
     size_t lds_small = (size_t)4 << a.hbits;
     if (lds_small < epilogue_bytes) lds_small = epilogue_bytes;
-    if constexpr (R >= 5 && !FILT) {
+    if constexpr (R >= 8 && !FILT) {
         // Searches that visit far more than a 16 KB LDS table holds: the whole visited set in HBM, one table per resident
-        // wave.  From ef 253 on only: below, the LDS table with a spill table behind it is as fast or faster now that a
+        // wave.  From ef 317 on only: below, the LDS table with a spill table behind it is as fast or faster now that a
         // launch cannot run out of spill tables (20 M x 128, 10 000 queries, LDS + spill against this: ef 200 6.4 / 7.0 ms,
-        // ef 300 9.5 / 9.6, ef 400 14.2 / 12.3, ef 508 23.2 / 15.7).
+        // ef 300 9.5 / 9.6, ef 400 14.2 / 12.3, ef 508 23.2 / 15.7; double hashing then took another 10 % off the
+        // left-hand numbers).
         if (a.hbits >= 13 && a.ghash) {
             // persistent blocks: as many as are resident at once, each with its own table
             static const uint32_t resident = [&] {
@@ -1115,6 +1123,13 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
         const size_t stage_bytes = FILT ? 0 : (size_t)64 * R * 8;
         b.lds_entries = (uint32_t)((lds_small - stage_bytes) / 4);
         b.stage_off = b.lds_entries;
+        auto is_prime = [](uint32_t v) {  // (a few trial divisions below 16 384)
+            for (uint32_t d = 2; d * d <= v; ++d)
+                if (v % d == 0u) return false;
+            return v >= 2u;
+        };
+        b.lds_mod = b.lds_entries;
+        while (!is_prime(b.lds_mod)) --b.lds_mod;
         // the spill variant costs the searches that never spill 1-5 % (a uniform branch per hop in the
         // hash probe): the caller passes the tables only when earlier launches at this ef needed them
         if (a.spill) {
@@ -1217,11 +1232,10 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
     // 2 500 nodes at the 75 % fill limit), whatever ef: a search that visits more carries on in a spill table, or is
     // re-run exactly by the large configuration.  `hbits` starts at 2^11 entries and is raised by the caller when more
     // than 2 % of a launch at this ef outgrew the table (next_hbits_bias): 2^12 entries take LDS from the residency, and
-    // from 2^13 on the searches with five or more key registers move their visited set to HBM altogether (launch_cfg).
+    // from 2^13 on the searches with eight key registers (ef > 316) move their visited set to HBM altogether (launch_cfg).
     // (round 1 sized the table by ef - 2^12 from ef 65 on, more by ef * maxM0 / 2: ef 100 then ran with 10 queries per CU)
     uint32_t hb = 11;
     hb += work.hbits_bias;
-    if (const char* e = std::getenv("VDB_HB")) hb = (uint32_t)std::atoi(e);  // TEMP experiment
     if (hb > 14) hb = 14;
     a.hbits = hb;
     a.allow = d_allow;
