@@ -165,6 +165,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sharded", action="store_true")
     ap.add_argument("--no-bruteforce", action="store_true", help="skip the configs[2] block of the default line")
+    ap.add_argument("--no-ef-block", action="store_true", help="skip the larger-ef block (traversal_by_ef) of the default line")
     ap.add_argument("--workload", choices=("hnsw", "bruteforce", "c4", "c5"), default="hnsw",
                     help="hnsw = BASELINE.json configs[1] (the headline metric, + the configs[2] block at N=1); "
                          "bruteforce = configs[2] alone; c4 / c5 = the sharded configurations configs[3] / configs[4]")
@@ -302,6 +303,36 @@ def run_hnsw(args, dd, rank, local_rank, world, dev, cores, threads):
     if rank == 0:
         log(f"timed: {elapsed / args.steps * 1e3:.4f} ms per step, {qps:.4e} queries/s over {world} rank(s)")
 
+    # ---- the same batch at larger ef (outside the timed region; not `value`): the traversal beyond the headline's ef is
+    # where C4 at high recall and C5 live, so its rate belongs in the driver's record too
+    by_ef = None
+    if rank == 0 and world == 1 and not args.no_ef_block:
+        by_ef = {}
+        for ef in (64, 100, 200):
+            h.setefSearch(ef)
+            _, lab_e, st_e = h.search_batch(dq, k, stats=True)
+            torch.cuda.synchronize()
+            st_e = st_e.cpu().numpy().view(np.uint32).astype(np.int64)
+            bytes_e = int((st_e[:, 0] * 4 * dim + st_e[:, 1] * 4 * (maxM0 + 1) + st_e[:, 2] * 4 * (maxM + 1)).sum()
+                          + args.nq * (4 * dim + k * 12))
+            for _ in range(3):   # (the library sizes its visited set from the reports of completed launches)
+                h.search_batch(dq, k)
+                torch.cuda.synchronize()
+            ev_e = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+            for a, b in ev_e:
+                a.record()
+                h.search_batch(dq, k)
+                b.record()
+            torch.cuda.synchronize()
+            ms_e = float(np.mean([a.elapsed_time(b) for a, b in ev_e]))
+            by_ef[str(ef)] = {"ms_per_batch": round(ms_e, 4), "queries_per_s": round(args.nq / ms_e * 1e3, 1),
+                              "recall_at_10": round(datasets.recall_at_k(lab_e.cpu().numpy().view(np.uint64), gt), 4),
+                              "mean_ndis": round(float(st_e[:, 0].mean()), 1), "mean_hops": round(float(st_e[:, 1].mean()), 1),
+                              "roofline": {"bound": "hbm", "achieved": round(bytes_e / ms_e / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": round(bytes_e / ms_e / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": bytes_e}}
+        h.setefSearch(chosen)
+        log("larger ef, same batch: " + ", ".join(f"ef {e}: {v['ms_per_batch']} ms ({v['roofline']['frac']:.2f} of HBM peak)" for e, v in by_ef.items()))
+
     # ---- sharded variant (north star): base split over ranks + RCCL all-gather + merge --
     sharded = None
     if world > 1 and not args.no_sharded:
@@ -409,6 +440,8 @@ def run_hnsw(args, dd, rank, local_rank, world, dev, cores, threads):
                      "algorithmic_bytes_per_launch": alg_bytes},
         "cpu_baseline": cpu,
     }
+    if by_ef is not None:
+        out["traversal_by_ef"] = by_ef
     if sharded is not None:
         out["sharded"] = sharded
     if bruteforce is not None:

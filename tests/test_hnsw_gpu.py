@@ -144,9 +144,10 @@ def test_spill_tables_at_small_ef(orc, monkeypatch, metric):
         assert_same_results((dist, label), o.search(q, 10), st)
 
 
-@pytest.mark.parametrize("ef,k", [(300, 300), (316, 100), (317, 10), (508, 508), (124, 124), (125, 100), (60, 60), (61, 50)])
+@pytest.mark.parametrize("ef,k", [(300, 300), (316, 100), (317, 10), (508, 508), (124, 124), (125, 100), (60, 60), (61, 50),
+                                  (188, 188), (189, 100), (252, 252), (253, 10)])
 def test_large_ef_and_key_array_boundaries(orc, ef, k):
-    """Every key-array size (1, 2, 4, 5, 8 registers per lane) at its boundary, k up to ef = 508."""
+    """Every key-array size (1, 2, 3, 4, 5, 8 registers per lane) at its boundaries, k up to ef = 508."""
     x = datasets.clustered(20000, 24, 13)
     q = datasets.clustered(64, 24, 14)
     h, o = build_pair(orc, x, vi.L2, 16, 100, n_threads=4)
