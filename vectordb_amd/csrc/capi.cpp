@@ -112,6 +112,7 @@ struct SearchScratch {
     DevBuf spill;                 // second-level visited tables for the queries that fill their LDS table
     DevBuf heaps;                 // candidate heaps of hnsw_search_unbounded_kernel (filtered searches; allocated on first need)
     uint32_t heap_cap = 0, heap_blocks = 0;
+    uint32_t large_blocks = kLargeBlocks;  // bitmaps held (scratch_for)
     uint32_t spill_tables = 0;
     // host-mapped {re-run queries, nq} written by the last launch on this stream, and the ef it ran at:
     // read (without synchronising) before the next launch to size the visited set (see search_device)
@@ -460,7 +461,13 @@ SearchScratch& scratch_for(vdb_index* idx, hipStream_t stream, size_t nq) {
     const uint32_t words = (idx->graph.n + 31u) / 32u;
     if (!s.bitmaps.p || s.bitmap_words < words) {
         if (s.bitmaps.p) VDB_HIP(hipStreamSynchronize(stream));
-        s.bitmaps.alloc((size_t)kLargeBlocks * std::max(words, 1u) * 4);
+        // The large configuration re-runs what the first level gives up on, one resident wave per bitmap.  With 128 of
+        // them a batch that overflows wholesale (a filter that keeps half the elements at ef 64 fills the 128 keys of
+        // the first level: all 10 000 queries) ran 52 ms on a 1 M-element graph; as many as fit 256 MB, up to the 2 048
+        // that can be resident, take it to a few ms.  Above 16 M elements it is 128 again.
+        const size_t one = (size_t)std::max(words, 1u) * 4;
+        s.large_blocks = (uint32_t)std::min<size_t>(kLargeBlocksMax, std::max<size_t>(kLargeBlocks, kLargeBitmapBytes / one));
+        s.bitmaps.alloc((size_t)s.large_blocks * one);
         s.bitmap_words = std::max(words, 1u);
     }
     return s;
@@ -562,6 +569,7 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
     }
     work.bitmaps = (uint32_t*)s.bitmaps.p;
     work.bitmap_words = s.bitmap_words;
+    work.large_blocks = s.large_blocks;
     if (ef > 124 && !allow) {
         if (!s.ghash.p) s.ghash.alloc(((size_t)kGlobalHashBlocks << kGlobalHashBits) * 4);
         work.ghash = (uint32_t*)s.ghash.p;
@@ -572,7 +580,7 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
         const uint32_t cap = (uint32_t)std::min<size_t>(idx->graph.n, (size_t)1 << 25);
         if (s.heap_cap < cap) {
             if (s.heaps.p) VDB_HIP(hipStreamSynchronize(stream));
-            const uint32_t blocks = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, ((size_t)256 << 20) / ((size_t)cap * 8)));
+            const uint32_t blocks = (uint32_t)std::max<size_t>(1, std::min<size_t>(64, ((size_t)256 << 20) / ((size_t)cap * 8)));
             s.heaps.alloc((size_t)blocks * cap * 8);
             s.heap_cap = cap;
             s.heap_blocks = blocks;
@@ -773,6 +781,7 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
     work.redo = (uint32_t*)sc->redo.p;
     work.bitmaps = (uint32_t*)sc->bitmaps.p;
     work.bitmap_words = sc->bitmap_words;
+    work.large_blocks = sc->large_blocks;
     // the visited-set size follows what the rounds report, as in search_device: the searches of a
     // large graph at ef_construction visit more nodes than the default table holds, and the large
     // configuration (an n-bit map per re-run query) is no place for a whole batch

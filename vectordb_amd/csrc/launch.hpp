@@ -15,7 +15,9 @@ constexpr uint32_t kMaxVecStride = 1024;   // floats per row (16 chunks of 64)
 constexpr uint32_t kMaxL0Stride = 64;      // layer-0 list slots (maxM0 <= 64, i.e. M <= 32)
 constexpr uint32_t kGlobalHashBits = 15;     // 32 768 entries (128 KB) per resident wave: 24 576 visited nodes
 constexpr uint32_t kGlobalHashBlocks = 4096;  // resident waves of the global-hash configuration (512 MB of tables)
-constexpr uint32_t kLargeBlocks = 128;     // resident waves of the large configuration (one bitmap each)
+constexpr uint32_t kLargeBlocks = 128;     // resident waves of the large configuration (one n-bit bitmap each), at least; as many
+constexpr uint32_t kLargeBlocksMax = 2048; // more, up to 2048 (8 per CU by its registers), as fit kLargeBitmapBytes
+constexpr size_t kLargeBitmapBytes = (size_t)256 << 20;
 constexpr uint32_t kSpillBits = 14;        // 16 384 entries (64 KB) per spill table: 12 288 more visited nodes
 constexpr uint32_t kSpillTablesMin = 512;  // spill tables per launch: nq within [512, 4096] (32-256 MB).  A table goes back when its
 constexpr uint32_t kSpillTablesMax = 4096; // query ends, and a GPU holds at most 4096 of these searches at once (16 per CU by
