@@ -118,6 +118,7 @@ struct SearchScratch {
     // read (without synchronising) before the next launch to size the visited set (see search_device)
     uint32_t* report = nullptr;
     uint32_t report_ef = 0;
+    bool report_filtered = false;
     // recorded behind the launch that writes `report`; the words are read (and the next observation
     // armed) only once it has completed, so what a launch adapts to never depends on timing
     hipEvent_t report_done = nullptr;
@@ -161,6 +162,7 @@ struct vdb_index {
     DevBuf live;  // bit i = element i is not deleted; allocated only when the upload saw deleted elements
     std::map<uint32_t, uint32_t> hbits_bias;  // per ef: extra log2 of the visited-set size (guarded by scratch_lock)
     std::set<uint32_t> spill_ef;              // the ef values at which a launch had queries outgrow the LDS table (same lock)
+    std::map<uint32_t, uint32_t> filt_level;  // per ef, filtered searches: steps up in key registers of the first level (same lock)
     int spill_mode = spill_mode_from_env();   // -1 adaptive, 0 never, 1 always (read once, at creation)
     std::mutex scratch_lock;
     std::map<hipStream_t, std::unique_ptr<SearchScratch>> scratch;
@@ -534,8 +536,8 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
     // the data.  Each launch reports how many queries outgrew it, and next_hbits_bias (launch.hpp)
     // decides whether the next launches at this ef get a table twice the size (sticky, at most 2^14 entries).
     if (!s.report) {
-        VDB_HIP(hipHostMalloc((void**)&s.report, 8, hipHostMallocMapped));
-        s.report[0] = s.report[1] = 0;
+        VDB_HIP(hipHostMalloc((void**)&s.report, 16, hipHostMallocMapped));
+        s.report[0] = s.report[1] = s.report[2] = s.report[3] = 0;
         VDB_HIP(hipEventCreateWithFlags(&s.report_done, hipEventDisableTiming));
     }
     // One observation per launch, taken only when the launch that wrote the words has completed
@@ -544,13 +546,21 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
     bool arm_report = true;
     if (s.report_pending) {
         if (hipEventQuery(s.report_done) == hipSuccess) {
-            const uint32_t redone = s.report[0], of = s.report[1];
+            // (a query whose key array overflowed says nothing about the visited table)
+            const uint32_t keys = s.report[2], redone = s.report[0] - std::min(s.report[0], keys), of = s.report[1];
             if (of != 0 && s.report_ef != 0) {
                 if (redone != 0) idx->spill_ef.insert(s.report_ef);
                 uint32_t& b = idx->hbits_bias[s.report_ef];
                 b = next_hbits_bias(b, redone, of);
+                // filtered searches: the first level's key array holds the ef results AND the live candidates outside
+                // them, about ef / selectivity keys; when more than 2 % of a launch outgrew it the next filtered launches
+                // at this ef start with twice the key registers (sticky; 2 -> 4 -> 8)
+                if (s.report_filtered && (uint64_t)keys * 50u > of) {
+                    uint32_t& lv = idx->filt_level[s.report_ef];
+                    if (lv < 2) lv += 1;
+                }
             }
-            s.report[0] = s.report[1] = 0;
+            s.report[0] = s.report[1] = s.report[2] = 0;
             s.report_pending = false;
         } else {
             (void)hipGetLastError();  // hipErrorNotReady is not an error here
@@ -595,6 +605,10 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
         auto it = idx->hbits_bias.find((uint32_t)ef);
         work.hbits_bias = it == idx->hbits_bias.end() ? 0u : it->second;
     }
+    if (allow) {
+        auto it = idx->filt_level.find((uint32_t)ef);
+        work.filt_level = it == idx->filt_level.end() ? 0u : it->second;
+    }
     if (stop) {
         uint32_t u;
         std::memcpy(&u, &stop->epsilon, 4);
@@ -610,6 +624,7 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
     if (rc != 0) return set_error(rc, err);
     if (arm_report) {
         s.report_ef = (uint32_t)ef;
+        s.report_filtered = allow != nullptr;
         VDB_HIP(hipEventRecord(s.report_done, stream));
         s.report_pending = true;
     }
@@ -786,8 +801,8 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
     // large graph at ef_construction visit more nodes than the default table holds, and the large
     // configuration (an n-bit map per re-run query) is no place for a whole batch
     if (!sc->report) {
-        VDB_HIP(hipHostMalloc((void**)&sc->report, 8, hipHostMallocMapped));
-        sc->report[0] = sc->report[1] = 0;
+        VDB_HIP(hipHostMalloc((void**)&sc->report, 16, hipHostMallocMapped));
+        sc->report[0] = sc->report[1] = sc->report[2] = sc->report[3] = 0;
         VDB_HIP(hipEventCreateWithFlags(&sc->report_done, hipEventDisableTiming));
     }
     if (sc->report_pending) {  // a query launch's observation still in flight: let it land, then drop it

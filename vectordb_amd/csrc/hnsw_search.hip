@@ -377,6 +377,7 @@ struct SearchArgs {
     uint32_t eps_ord;      // FILT only: the epsilon stop condition (HnswSearchWork), kEmptyWord = none
     uint32_t eps_min;
     uint32_t* fail_list;   // nullable: queries the large configuration could not answer, for hnsw_search_unbounded_kernel
+    uint32_t filt_level;   // host side only: see HnswSearchWork
     uint64_t* heaps;       // [heap_blocks][heap_cap]
     uint32_t heap_cap, heap_blocks;
 };
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
             const uint32_t spilled = a.redo[2];
             a.report[0] = n_work + spilled;  // the queries that outgrew the LDS table, whichever way they went on
             a.report[1] = a.nq;
+            a.report[2] = a.redo[kRedoKeyOverflow];
         }
     }
 #pragma unroll 1
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
             bound = ef > 1 ? kEmptyWord : cur_d;  // hi of entry ef-1
         }
         uint32_t nvis = 1, vis_limit = vis.limit();
-        bool overflow = false;
+        bool overflow = false, key_overflow = false;
         if (lane == 0) (void)vis.test_and_set(cur);
 
         // Link rows fetched ahead of need (hints only: a wrong guess costs one 128-B load).
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
                 if constexpr (!FILT) {
                     if (trim_due) arr.trim(ef, bound, lane);
                 }
-                if (ballot(lost)) overflow = true;  // (any lane: the merge loses keys from every lane that moves past the end)
+                if (ballot(lost)) overflow = key_overflow = true;  // (any lane: the merge loses keys from every lane that moves past the end)
             }
             if (overflow) break;
         }
@@ -715,6 +717,7 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
                 if (lane == 0) {
                     const uint32_t slot = atomicAdd(&a.redo[0], 1u);
                     a.redo[kRedoHeader + slot] = qi;
+                    if (FILT && key_overflow) atomicAdd(&a.redo[kRedoKeyOverflow], 1u);  // (the host sizes the next launches' arrays)
                 }
                 continue;
             } else {
@@ -1175,8 +1178,11 @@ int launch_r(const SearchArgs& a, hipStream_t stream, std::string* err) {
         // filtered: the array also holds the live candidates that are not results (about
         // ef / selectivity keys in all) - twice the registers of the bare search, and 1024 keys in
         // the large configuration
-        if (a.ef <= 64) return launch_cfg<NCH, GPB, 2, 16, true>(a, stream, err);
-        if (a.ef <= 128) return launch_cfg<NCH, GPB, 4, 16, true>(a, stream, err);
+        // (the caller raises filt_level when launches at this ef report key-array overflows: a filter that keeps half
+        // the elements at ef 64 holds 128 live keys, one that keeps a tenth at ef 32 holds 320)
+        const uint32_t level = (a.ef <= 64 ? 0u : a.ef <= 128 ? 1u : 2u) + a.filt_level;
+        if (level == 0) return launch_cfg<NCH, GPB, 2, 16, true>(a, stream, err);
+        if (level == 1) return launch_cfg<NCH, GPB, 4, 16, true>(a, stream, err);
         return launch_cfg<NCH, GPB, 8, 16, true>(a, stream, err);
     }
     // capacity 64 R > ef: with capacity == ef every tie at the bound that is pushed off the end sends
@@ -1248,6 +1254,7 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
     a.bitmaps = work.bitmaps;
     a.bitmap_words = work.bitmap_words;
     a.large_blocks = work.large_blocks ? work.large_blocks : 1u;
+    a.filt_level = work.filt_level;
     a.ghash = work.ghash;
     a.report = work.report;
     a.eps_ord = work.eps_ord;
