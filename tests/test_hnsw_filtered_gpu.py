@@ -83,6 +83,27 @@ def test_filter_functor(orc, mod, keep, ef):
     assert [b for _, b in one] == [int(v) for v in l[0] if v != np.uint64(0xFFFFFFFFFFFFFFFF)]
 
 
+@pytest.mark.parametrize("mod,ef", [(2, 64), (4, 40), (10, 32), (3, 128)])
+def test_repeated_filtered_launches_adapt_and_stay_exact(orc, mod, ef):
+    """The first level of a filtered search holds 128 keys at ef <= 64 (256 at ef <= 128): a filter that keeps 1/mod of
+    the elements needs about ef * mod.  The first launch re-runs the overflowing queries in the large configuration, the
+    report of that launch doubles the key registers of the next ones at this ef (twice, if need be): every launch equals
+    the oracle, whichever kernels answered it."""
+    n, dim = 20000, 24
+    x = datasets.clustered(n, dim, 71)
+    q = datasets.clustered(600, dim, 72)
+    h, o = build_pair(orc, x, n_threads=4)
+    h.to_device(0)
+    h.setefSearch(ef)
+    o.set_ef(ef)
+    r = o.search(q, 10, filter_mod=mod, filter_keep=1)
+    for _ in range(4):   # (search_batch on host arrays returns after the launch has completed: each report is read by the next)
+        d, l, st = h.search_batch(q, 10, stats=True, filter=lambda lab: lab % mod == 1)
+        assert_same_results((d, l), r, st)
+    # an unfiltered search at the same ef is not disturbed by what the filtered ones reported
+    assert_same_results(h.search_batch(q, 10, stats=True)[:2], o.search(q, 10), h.search_batch(q, 10, stats=True)[2])
+
+
 def test_filter_and_deleted_on_device_tensors(orc):
     import torch
     n, dim = 5000, 24
