@@ -573,7 +573,11 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
     // had queries outgrow the LDS table: the kernel variant that can spill is 1-5 % slower for the
     // searches that never do.  vdb_index_set_spill_mode / VDB_SPILL at creation (tests) = never / always.
     {
-        const bool on = idx->spill_mode >= 0 ? idx->spill_mode == 1 : idx->spill_ef.count((uint32_t)ef) != 0;
+        // (from 4 M elements on and ef >= 64 also on the first launch at an ef: searches of such graphs visit more than
+        // the LDS table holds as a rule, and the large configuration has 128 waves for them there - 10 000 queries on a
+        // 100 M-element graph would wait 80 ms for their first answer)
+        const bool on = idx->spill_mode >= 0 ? idx->spill_mode == 1
+                                             : idx->spill_ef.count((uint32_t)ef) != 0 || (idx->graph.n >= (1u << 22) && ef >= 64);
         work.spill = on ? (uint32_t*)s.spill.p : nullptr;
         work.spill_tables = s.spill_tables;
     }
