@@ -612,6 +612,15 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
     if (allow) {
         auto it = idx->filt_level.find((uint32_t)ef);
         work.filt_level = it == idx->filt_level.end() ? 0u : it->second;
+        // What the host knows ahead of any report: with a fraction f of the elements deleted the array holds about
+        // ef / (1 - f) live keys (a filter on top of that only adds to it).
+        const size_t n = idx->graph.n, dead = std::min<size_t>(idx->host->deleted, n);
+        if (n != 0 && dead != 0 && dead < n) {
+            const double need = 1.25 * (double)ef * (double)n / (double)(n - dead);
+            uint32_t cap = ef <= 64 ? 128u : ef <= 128 ? 256u : 512u, lv = 0;
+            while (lv < 2 && cap < 512u && (double)cap < need) cap *= 2, lv += 1;
+            work.filt_level = std::max(work.filt_level, lv);
+        }
     }
     if (stop) {
         uint32_t u;
