@@ -35,6 +35,7 @@ while time.time() - t0 < budget:
     q = np.ascontiguousarray(q, np.float32)
     h, o = build_pair(orc, x, metric, M, int(rng.choice([32, 100, 200])), n_threads=4)
     h.to_device(0)
+    h.set_spill_mode(int(rng.choice([-1, -1, 0, 1])))   # adaptive / never / always second-level visited tables
     for _ in range(4):
         ef = int(rng.choice([1, 7, 32, 60, 61, 100, 124, 125, 160, 188, 189, 252, 253, 300, 400]))
         k = int(min(ef, rng.choice([1, 5, 10, 100])))
