@@ -2,7 +2,7 @@
 """Randomised parity sweep (not collected by pytest; run by hand on a GPU box):
     python tests/fuzz_parity.py [seconds] [seed]
 Random graphs (size, dim, M, metric, quantised coordinates for exact distance ties, duplicated rows), random ef / k,
-bare and filtered, several launches per index so that the adaptive state (visited-table size, spill tables, key-array
+bare and filtered, one epsilon stop-condition search per graph, several launches per index so that the adaptive state (visited-table size, spill tables, key-array
 level) moves under the comparison.  Every launch must equal the oracle bit for bit: ids, distances, counters."""
 import os, sys, time
 import numpy as np
@@ -48,6 +48,19 @@ while time.time() - t0 < budget:
             ok = st[:, 3] != 0xFFFFFFFF   # (hundreds of keys AT the bound's distance: flagged, never truncated; see the tests)
             assert_same_results((d[ok], l[ok]), {key: v[ok] for key, v in ref.items() if key != "seconds"}, st[ok])
             launches += 1
+    # the stop-condition search (epsilon radius): a radius drawn from the distances just seen
+    if np.isfinite(ref["dist"]).any():
+        eps = float(rng.choice(ref["dist"][np.isfinite(ref["dist"])]))
+        mx = int(rng.choice([1, 16, 64, 200])); mn = int(rng.integers(1, mx + 1))
+        mod = int(rng.choice([0, 0, 3]))
+        r = o.search_epsilon(q, eps, mn, mx, filter_mod=mod, filter_keep=1 % max(mod, 1)) if mod else o.search_epsilon(q, eps, mn, mx)
+        d, l, cnt, st = h.search_stop_condition_closest_batch(q, eps, mn, mx, filter=(lambda lab, m=mod: lab % m == 1 % m) if mod else None)
+        np.testing.assert_array_equal(cnt, r["count"])
+        np.testing.assert_array_equal(l, r["label"].astype(np.uint64))
+        np.testing.assert_array_equal(d.view(np.uint32), r["dist"].view(np.uint32))
+        np.testing.assert_array_equal(st[:, 0], r["ndis"].astype(np.uint32))
+        np.testing.assert_array_equal(st[:, 1], r["nhops0"].astype(np.uint32))
+        launches += 1
     cases += 1
     if cases % 5 == 0:
         print(f"{cases} graphs, {launches} launches equal to the oracle, {time.time() - t0:.0f}s", flush=True)
