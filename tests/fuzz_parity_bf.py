@@ -14,7 +14,7 @@ from vectordb_amd import datasets, index as vi
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 200.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 777)
 orc.build()
-t0, cases = time.time(), 0
+t0, cases, filtered = time.time(), 0, 0
 while time.time() - t0 < budget:
     dim = int(rng.choice([8, 40, 96, 128, 200, 512, 960]))
     nq = int(rng.choice([5, 37, 150, 700]))
@@ -51,7 +51,13 @@ while time.time() - t0 < budget:
     hit = sum(len(set(a[a != pad]) & set(c[c != pad])) for a, c in zip(l2, l))
     assert hit >= 0.99 * int((l != pad).sum()), (n, dim, k, metric, style)
     np.testing.assert_array_equal(l2 == pad, l == pad)
+    if rng.random() < 0.5:   # with a filter functor (bruteforce.hpp:158-173): label % 7 == 2
+        rf = ob.search(q, k, filter_mod=7, filter_keep=2)
+        df, lf = b.search_batch(q, k, precision=vi.BF_FP32, filter=lambda lab: lab % 7 == 2)
+        np.testing.assert_array_equal(lf, rf["label"].astype(np.uint64))
+        np.testing.assert_array_equal(df.view(np.uint32), rf["dist"].view(np.uint32))
+        filtered += 1
     cases += 1
     if cases % 10 == 0:
         print(f"{cases} base sets equal to the oracle, {time.time() - t0:.0f}s", flush=True)
-print(f"done: {cases} base sets, fp32 equal to the oracle bit for bit, bf16 + re-rank recall >= 0.99")
+print(f"done: {cases} base sets ({filtered} also with a filter), fp32 equal to the oracle bit for bit, bf16 + re-rank recall >= 0.99")
