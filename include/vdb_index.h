@@ -75,6 +75,16 @@ void vdb_index_free(vdb_index* idx);
  * reference's semantics (same graph as the reference algorithm for the same insertion
  * order, seed and summation order).  `level` < 0 draws the level (hnsw_core.hpp:240-244). */
 int vdb_index_add(vdb_index* idx, const float* vec, uint64_t label, int level);
+/* addPoint(datapoint, label, replace_deleted), hnsw_core.hpp:804-842.  A label the index holds already is UPDATED
+ * in place (hnsw_core.hpp:1001-1016 -> updatePoint :844-913 -> repairConnectionsForUpdate :924-980; a deleted
+ * element comes back to life); vdb_index_add does the same.  With replace_deleted != 0 the element takes the place
+ * of a deleted one when there is any (:815-841: the smallest vacant internal id; the reference takes an unspecified
+ * one) and is appended otherwise; VDB_ERR_RUNTIME "Replacement of deleted elements is disabled in constructor"
+ * unless vdb_index_set_reuse_deleted switched it on (:805-807). */
+int vdb_index_add_point(vdb_index* idx, const float* vec, uint64_t label, int replace_deleted);
+/* The constructors' reuse_deleted flag, hnsw_core.hpp:114, :123 (and :672-677: elements already marked deleted
+ * become vacant places).  With it on, vdb_index_add on the label of a DELETED element is refused (:1003-1007). */
+int vdb_index_set_reuse_deleted(vdb_index* idx, int on);
 /* n addPoint calls; labels NULL = 0..n-1 continuing from the current count.  n_threads > 1
  * inserts concurrently as the reference allows (label stripes, per-node link locks,
  * global lock: hnsw_core.hpp:77-84); the link order is then not reproducible. */
@@ -104,6 +114,9 @@ int vdb_index_set_spill_mode(vdb_index* idx, int mode);
 /* markDelete / unmarkDelete, hnsw_core.hpp:709-782. */
 int vdb_index_mark_delete(vdb_index* idx, uint64_t label);
 int vdb_index_unmark_delete(vdb_index* idx, uint64_t label);
+/* getDataByLabel, hnsw_core.hpp:683-703: the stored vector (dim floats); "Label not found" for an unknown or a
+ * deleted label. */
+int vdb_index_get_data_by_label(const vdb_index* idx, uint64_t label, float* out);
 /* resizeIndex, hnsw_core.hpp:500-522. */
 int vdb_index_resize(vdb_index* idx, size_t new_capacity);
 /* checkIntegrity, hnsw_core.hpp:1216-1245: 0 ok, else 1 id out of range, 2 self link,

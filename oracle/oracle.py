@@ -45,6 +45,11 @@ def _sig(lib):
     lib.orc_hnsw_create.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
     lib.orc_hnsw_load.restype = C.c_void_p
     lib.orc_hnsw_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_size_t]
+    lib.orc_hnsw_create_reuse.restype = C.c_void_p
+    lib.orc_hnsw_create_reuse.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+    lib.orc_hnsw_load_reuse.restype = C.c_void_p
+    lib.orc_hnsw_load_reuse.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_size_t, C.c_int]
+    lib.orc_hnsw_add_replace.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_int]
     lib.orc_hnsw_free.argtypes = [C.c_void_p]
     lib.orc_hnsw_save.argtypes = [C.c_void_p, C.c_char_p]
     lib.orc_hnsw_add.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_int]
@@ -135,19 +140,19 @@ class OracleHNSW:
     """The restated HierarchicalNSW<float> (hnsw_core.hpp:21)."""
 
     def __init__(self, metric: int, dim: int, capacity: int = 0, M: int = 16, ef_construction: int = 200,
-                 seed: int = 100, mode: int = SEQ, o3: bool = False, path: str | None = None):
+                 seed: int = 100, mode: int = SEQ, o3: bool = False, path: str | None = None, reuse_deleted: bool = False):
         self._l = lib(o3)
         self.metric, self.dim = metric, dim
         if path is not None:
-            self._h = self._l.orc_hnsw_load(path.encode(), metric, mode, dim)
+            self._h = self._l.orc_hnsw_load_reuse(path.encode(), metric, mode, dim, int(reuse_deleted))
         else:
-            self._h = self._l.orc_hnsw_create(metric, mode, dim, capacity, M, ef_construction, seed)
+            self._h = self._l.orc_hnsw_create_reuse(metric, mode, dim, capacity, M, ef_construction, seed, int(reuse_deleted))
         if not self._h:
             raise RuntimeError(_err(self._l))
 
     @classmethod
-    def load(cls, path: str, metric: int, dim: int, mode: int = SEQ, o3: bool = False) -> "OracleHNSW":
-        return cls(metric, dim, mode=mode, o3=o3, path=path)
+    def load(cls, path: str, metric: int, dim: int, mode: int = SEQ, o3: bool = False, reuse_deleted: bool = False) -> "OracleHNSW":
+        return cls(metric, dim, mode=mode, o3=o3, path=path, reuse_deleted=reuse_deleted)
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -166,6 +171,12 @@ class OracleHNSW:
     def add_one(self, vec, label: int, level: int = -1) -> None:
         vec, pv = _f32(vec)
         if self._l.orc_hnsw_add(self._h, pv, label, level) != 0:
+            raise RuntimeError(_err(self._l))
+
+    def add_point(self, vec, label: int, replace_deleted: bool = False) -> None:
+        """addPoint(datapoint, label, replace_deleted), hnsw_core.hpp:804-842: updates the element when the label exists."""
+        vec, pv = _f32(vec)
+        if self._l.orc_hnsw_add_replace(self._h, pv, label, int(replace_deleted)) != 0:
             raise RuntimeError(_err(self._l))
 
     def save(self, path: str) -> None:

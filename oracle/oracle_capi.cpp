@@ -63,6 +63,32 @@ void* orc_hnsw_load(const char* path, int metric, int mode, size_t dim) {
         return nullptr;
     }
 }
+// the constructors' reuse_deleted flag (hnsw_core.hpp:114, :123)
+void* orc_hnsw_create_reuse(int metric, int mode, size_t dim, size_t capacity, size_t M, size_t efc, size_t seed, int reuse_deleted) {
+    try {
+        return new HierarchicalNSW(make_space(metric, mode, dim), capacity, M, efc, seed, reuse_deleted != 0);
+    } catch (const std::exception& e) {
+        fail(e);
+        return nullptr;
+    }
+}
+void* orc_hnsw_load_reuse(const char* path, int metric, int mode, size_t dim, int reuse_deleted) {
+    try {
+        return new HierarchicalNSW(make_space(metric, mode, dim), std::string(path), 0, reuse_deleted != 0);
+    } catch (const std::exception& e) {
+        fail(e);
+        return nullptr;
+    }
+}
+// addPoint(datapoint, label, replace_deleted), hnsw_core.hpp:804-842
+int orc_hnsw_add_replace(void* h, const float* vec, size_t label, int replace_deleted) {
+    try {
+        static_cast<AlgorithmInterface*>(static_cast<HierarchicalNSW*>(h))->addPoint(vec, label, replace_deleted != 0);
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e);
+    }
+}
 void orc_hnsw_free(void* h) { delete static_cast<HierarchicalNSW*>(h); }
 int orc_hnsw_save(void* h, const char* path) {
     try {

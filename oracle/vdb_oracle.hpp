@@ -47,6 +47,7 @@
 #include <memory>
 #include <mutex>
 #include <queue>
+#include <set>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -366,14 +367,21 @@ public:
 
     Space space_;
     LevelRng level_rng_;
+    LevelRng update_rng_;  // hnsw_core.hpp:93, :146: seeded random_seed + 1, drawn once per one-hop neighbour in updatePoint
     std::unique_ptr<VisitedListPool> visited_pool_;
+
+    // hnsw_core.hpp:103-105.  DEVIATION: an ordered set - the reference takes `*deleted_elements_.begin()` of an
+    // unordered_set (:820), i.e. an unspecified element; here the vacant place reused first is the smallest id.
+    bool reuse_deleted_ = false;
+    std::mutex deleted_elements_lock_;
+    std::set<idx_t> deleted_elements_;
 
     // hnsw_core.hpp:118-179  (DEVIATION: efConstruction_/efSearch_ are assigned to the
     // members — the reference assigns to the parameter / an undeclared name; entry and
     // max level start at -1 as :165-166 say).
     HierarchicalNSW(const Space& space, size_t capacity, size_t M = 16, size_t efConstruction = 200,
-                    size_t random_seed = 100)
-        : element_levels_(capacity), link_locks_(capacity), space_(space) {
+                    size_t random_seed = 100, bool reuse_deleted = false)
+        : element_levels_(capacity), link_locks_(capacity), space_(space), reuse_deleted_(reuse_deleted) {
         capacity_ = capacity;
         data_size_ = space.get_data_size();
         M_ = M <= 10000 ? M : 10000;
@@ -382,6 +390,7 @@ public:
         efConstruction_ = std::max(efConstruction, M_);
         efSearch_ = 10;
         level_rng_.seed(random_seed);
+        update_rng_.seed(random_seed + 1);  // :146
 
         link0_stride_ = max_M0_ * sizeof(idx_t) + sizeof(idx_t);
         element_stride_ = link0_stride_ + data_size_ + sizeof(label_t);
@@ -403,7 +412,8 @@ public:
     }
 
     // hnsw_core.hpp:110-116
-    HierarchicalNSW(const Space& space, const std::string& location, size_t capacity = 0) : space_(space) {
+    HierarchicalNSW(const Space& space, const std::string& location, size_t capacity = 0, bool reuse_deleted = false)
+        : space_(space), reuse_deleted_(reuse_deleted) {
         loadIndex(location, capacity);
     }
 
@@ -673,20 +683,166 @@ public:
         return next_closest;
     }
 
-    // hnsw_core.hpp:804-842.  DEVIATION: the replace-deleted and update-in-place paths
-    // (:815-841, :844-980) are not restated; asking for either throws.
+    // hnsw_core.hpp:804-842
     void addPoint(const void* data_point, label_t label, bool replace_deleted = false) override {
-        if (replace_deleted) throw std::runtime_error("Replacement of deleted elements is disabled in constructor");
-        addPoint(data_point, label, -1);
+        if (reuse_deleted_ == false && replace_deleted == true)
+            throw std::runtime_error("Replacement of deleted elements is disabled in constructor");
+        if (!replace_deleted) {
+            addPoint(data_point, label, -1);
+            return;
+        }
+        // check if there is vacant place
+        idx_t internal_id_replaced = 0;
+        std::unique_lock<std::mutex> lock_deleted_elements(deleted_elements_lock_);
+        bool is_vacant_place = !deleted_elements_.empty();
+        if (is_vacant_place) {
+            internal_id_replaced = *deleted_elements_.begin();
+            deleted_elements_.erase(internal_id_replaced);
+        }
+        lock_deleted_elements.unlock();
+        if (!is_vacant_place) {
+            addPoint(data_point, label, -1);
+        } else {
+            label_t label_replaced = getExternalLabel(internal_id_replaced);
+            memcpy(level0_data_ + (size_t)internal_id_replaced * element_stride_ + label_offset_, &label, sizeof(label_t));  // setExternalLabel
+            std::unique_lock<std::mutex> lock_table(label_map_lock_);
+            label_map_.erase(label_replaced);
+            label_map_[label] = internal_id_replaced;
+            lock_table.unlock();
+            unmarkDeletedInternal(internal_id_replaced);
+            updatePoint(data_point, internal_id_replaced, 1.0f);
+        }
+    }
+
+    // hnsw_core.hpp:983-991
+    std::vector<idx_t> getConnectionsWithLock(idx_t id, int level) {
+        std::unique_lock<std::mutex> lock(link_locks_[id]);
+        idx_t* data = get_neighbors_at_level(id, level);
+        int size = getListCount(data);
+        std::vector<idx_t> result(size);
+        memcpy(result.data(), data + 1, size * sizeof(idx_t));
+        return result;
+    }
+
+    // hnsw_core.hpp:844-913 (`elemLevel` / `entryPointCopy` at :912 read as the locals declared at :848, :851).
+    // DEVIATION: candidate_set / neighbor_set are ordered sets.  The reference walks two unordered_sets; the lists it
+    // writes do not depend on the order the NEIGHBOURS are taken in (each list is rebuilt from distances alone), but
+    // which of several candidates at exactly the same distance survive `distance < candidates.top().first` (:888) does
+    // depend on the order the CANDIDATES are met in: ascending id here, and (dist, id) order in the heap as everywhere.
+    void updatePoint(const void* dataPoint, idx_t internalId, float updateNeighborProbability) {
+        memcpy(getDataByInternalId(internalId), dataPoint, data_size_);
+        int maxLevelCopy = max_level_;
+        idx_t entryPointCopy = entry_id_;
+        if (entryPointCopy == internalId && element_count_ == 1) return;
+        int elemLevel = element_levels_[internalId];
+        for (int layer = 0; layer <= elemLevel; layer++) {
+            std::set<idx_t> sCand, sNeigh;
+            std::vector<idx_t> listOneHop = getConnectionsWithLock(internalId, layer);
+            if (listOneHop.size() == 0) continue;
+            sCand.insert(internalId);
+            for (idx_t elOneHop : listOneHop) {
+                sCand.insert(elOneHop);
+                // :865 std::uniform_real_distribution<float>(0,1)(update_rng_): one draw of the engine (24 bits wanted, 30 had)
+                const float u = (float)((double)(update_rng_.next() - 1) / 2147483646.0);
+                if (u > updateNeighborProbability) continue;
+                sNeigh.insert(elOneHop);
+                std::vector<idx_t> listTwoHop = getConnectionsWithLock(elOneHop, layer);
+                for (idx_t elTwoHop : listTwoHop) sCand.insert(elTwoHop);
+            }
+            for (idx_t neigh : sNeigh) {
+                ResultHeap candidates;
+                size_t size = sCand.find(neigh) == sCand.end() ? sCand.size() : sCand.size() - 1;
+                size_t elementsToKeep = std::min(efConstruction_, size);
+                for (idx_t cand : sCand) {
+                    if (cand == neigh) continue;
+                    float distance = space_(getDataByInternalId(neigh), getDataByInternalId(cand));
+                    if (candidates.size() < elementsToKeep) {
+                        candidates.emplace(distance, cand);
+                    } else if (distance < candidates.top().first) {
+                        candidates.pop();
+                        candidates.emplace(distance, cand);
+                    }
+                }
+                getNeighborsByHeuristic2(candidates, layer == 0 ? max_M0_ : max_M_);
+                {
+                    std::unique_lock<std::mutex> lock(link_locks_[neigh]);
+                    idx_t* ll_cur = get_neighbors_at_level(neigh, layer);
+                    size_t candSize = candidates.size();
+                    setListCount(ll_cur, (unsigned short)candSize);
+                    idx_t* data = ll_cur + 1;
+                    for (size_t idx = 0; idx < candSize; idx++) {
+                        data[idx] = candidates.top().second;
+                        candidates.pop();
+                    }
+                }
+            }
+        }
+        repairConnectionsForUpdate(dataPoint, entryPointCopy, internalId, elemLevel, maxLevelCopy);
+    }
+
+    // hnsw_core.hpp:924-980
+    void repairConnectionsForUpdate(const void* dataPoint, idx_t entryPointInternalId, idx_t dataPointInternalId,
+                                    int dataPointLevel, int maxLevel) {
+        idx_t currObj = entryPointInternalId;
+        if (dataPointLevel < maxLevel) {
+            float curdist = space_(dataPoint, getDataByInternalId(currObj));
+            for (int level = maxLevel; level > dataPointLevel; level--) {
+                bool changed = true;
+                while (changed) {
+                    changed = false;
+                    std::unique_lock<std::mutex> lock(link_locks_[currObj]);
+                    idx_t* data = get_neighbors_at_level(currObj, level);
+                    int size = getListCount(data);
+                    idx_t* datal = data + 1;
+                    for (int i = 0; i < size; i++) {
+                        idx_t cand = datal[i];
+                        float d = space_(dataPoint, getDataByInternalId(cand));
+                        if (d < curdist) {
+                            curdist = d;
+                            currObj = cand;
+                            changed = true;
+                        }
+                    }
+                }
+            }
+        }
+        if (dataPointLevel > maxLevel) throw std::runtime_error("Level of item to be updated cannot be bigger than max level");
+        for (int level = dataPointLevel; level >= 0; level--) {
+            ResultHeap topCandidates = searchBaseLayer(currObj, dataPoint, level);
+            ResultHeap filteredTopCandidates;
+            while (topCandidates.size() > 0) {
+                if (topCandidates.top().second != dataPointInternalId) filteredTopCandidates.push(topCandidates.top());
+                topCandidates.pop();
+            }
+            // Since element_levels_ is being used to get `dataPointLevel`, there could be cases where `topCandidates` could just
+            // contain entry point itself.
+            if (filteredTopCandidates.size() > 0) {
+                bool epDeleted = isMarkedDeleted(entryPointInternalId);
+                if (epDeleted) {
+                    filteredTopCandidates.emplace(space_(dataPoint, getDataByInternalId(entryPointInternalId)), entryPointInternalId);
+                    if (filteredTopCandidates.size() > efConstruction_) filteredTopCandidates.pop();
+                }
+                currObj = mutuallyConnectNewElement(dataPoint, dataPointInternalId, filteredTopCandidates, level, true);
+            }
+        }
     }
 
     // hnsw_core.hpp:994-1104
     idx_t addPoint(const void* data_point, label_t label, int level) {
         idx_t cur_c = 0;
         {
+            // :997-1016: an element with the same label is UPDATED instead of created
             std::unique_lock<std::mutex> lock_table(label_map_lock_);
-            if (label_map_.find(label) != label_map_.end())
-                throw std::runtime_error("oracle: label already present (update path :1001-1016 not restated)");
+            auto search = label_map_.find(label);
+            if (search != label_map_.end()) {
+                idx_t existingInternalId = search->second;
+                if (reuse_deleted_ && isMarkedDeleted(existingInternalId))
+                    throw std::runtime_error("Can't use addPoint to update deleted elements if replacement of deleted elements is enabled.");
+                lock_table.unlock();
+                if (isMarkedDeleted(existingInternalId)) unmarkDeletedInternal(existingInternalId);
+                updatePoint(data_point, existingInternalId, 1.0f);
+                return existingInternalId;
+            }
             if (element_count_ >= capacity_) throw std::runtime_error("The number of elements exceeds the specified limit");
             cur_c = (idx_t)element_count_;
             element_count_++;
@@ -764,10 +920,17 @@ public:
         if (it == label_map_.end()) throw std::runtime_error("Label not found");
         idx_t id = it->second;
         lock.unlock();
+        markDeletedInternal(id);
+    }
+    void markDeletedInternal(idx_t id) {  // :728-741
         if (isMarkedDeleted(id)) throw std::runtime_error("The requested to delete element is already deleted");
         unsigned char* flag = ((unsigned char*)get_neighbors_L0(id)) + 2;
         *flag |= DELETE_MARK;
         deleted_count_ += 1;
+        if (reuse_deleted_) {
+            std::unique_lock<std::mutex> lock_deleted_elements(deleted_elements_lock_);
+            deleted_elements_.insert(id);
+        }
     }
     // hnsw_core.hpp:750-782
     void unmarkDelete(label_t label) {
@@ -776,10 +939,17 @@ public:
         if (it == label_map_.end()) throw std::runtime_error("Label not found");
         idx_t id = it->second;
         lock.unlock();
+        unmarkDeletedInternal(id);
+    }
+    void unmarkDeletedInternal(idx_t id) {  // :769-782
         if (!isMarkedDeleted(id)) throw std::runtime_error("The requested to undelete element is not deleted");
         unsigned char* flag = ((unsigned char*)get_neighbors_L0(id)) + 2;
         *flag &= ~DELETE_MARK;
         deleted_count_ -= 1;
+        if (reuse_deleted_) {
+            std::unique_lock<std::mutex> lock_deleted_elements(deleted_elements_lock_);
+            deleted_elements_.erase(id);
+        }
     }
 
     // hnsw_core.hpp:1107-1159, with the work counters of :1122-1123 returned per query.
@@ -984,7 +1154,10 @@ public:
         }
         deleted_count_ = 0;
         for (size_t i = 0; i < count; i++)
-            if (isMarkedDeleted((idx_t)i)) deleted_count_ += 1;
+            if (isMarkedDeleted((idx_t)i)) {
+                deleted_count_ += 1;
+                if (reuse_deleted_) deleted_elements_.insert((idx_t)i);  // :675
+            }
         in.close();
     }
 

@@ -31,6 +31,8 @@ SIGNATURES = {
     "vdb_index_save": (C.c_int, [_vp, C.c_char_p]),
     "vdb_index_free": (None, [_vp]),
     "vdb_index_add": (C.c_int, [_vp, _f32p, C.c_uint64, C.c_int]),
+    "vdb_index_add_point": (C.c_int, [_vp, _f32p, C.c_uint64, C.c_int]),
+    "vdb_index_set_reuse_deleted": (C.c_int, [_vp, C.c_int]),
     "vdb_index_add_batch": (C.c_int, [_vp, _f32p, _u64p, C.c_size_t, C.c_int]),
     "vdb_index_add_batch_device": (C.c_int, [_vp, _f32p, _u64p, C.c_size_t, C.c_int, C.c_int]),
     "vdb_index_set_build_sum_order": (C.c_int, [_vp, C.c_int]),
@@ -38,6 +40,7 @@ SIGNATURES = {
     "vdb_index_set_spill_mode": (C.c_int, [_vp, C.c_int]),
     "vdb_index_mark_delete": (C.c_int, [_vp, C.c_uint64]),
     "vdb_index_unmark_delete": (C.c_int, [_vp, C.c_uint64]),
+    "vdb_index_get_data_by_label": (C.c_int, [_vp, C.c_uint64, _f32p]),
     "vdb_index_resize": (C.c_int, [_vp, C.c_size_t]),
     "vdb_index_check_integrity": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vdb_index_capacity": (C.c_size_t, [_vp]),

@@ -11,6 +11,7 @@
 // CPU glue only: parsing, the per-key index table, the reply.  The search itself is the device path of vdb_hnsw.hpp.
 #pragma once
 #include <cerrno>
+#include <cmath>
 #include <cstdlib>
 #include <map>
 #include <memory>
@@ -39,7 +40,15 @@ public:
         if (!parse_vector(args, 3, args.size(), v)) return Serializer::serialize_error(out, kErrArg, "Invalid vector component\n");
         std::unique_lock<std::mutex> g(lock_);
         Slot* s = find(args[1]);
-        if (!s) s = &create(args[1], v.size());
+        if (!s) {
+            // the key enters the table only once its index exists: a constructor that throws (no device memory, a
+            // dimension the device path refuses) leaves no half-made slot behind for later commands to trip over
+            try {
+                s = &create(args[1], v.size());
+            } catch (const std::exception& e) {
+                return Serializer::serialize_error(out, kErrUnknown, std::string(e.what()) + "\n");
+            }
+        }
         if (s->dim != v.size()) return Serializer::serialize_error(out, kErrArg, "Vector has the wrong dimension for this key\n");
         try {
             if (s->index->getElementCount() == s->capacity) {  // grow as resizeIndex does (hnsw_core.hpp:500-522)
@@ -107,11 +116,18 @@ public:
         Serializer::serialize_integer(out, s ? (int64_t)s->index->getElementCount() : 0);
     }
 
+    // the index behind a key (nullptr: no such key), for the embedding server's own use (persistence, statistics)
+    HierarchicalNSW<float>* index(const std::string& key) {
+        std::unique_lock<std::mutex> g(lock_);
+        Slot* s = find(key);
+        return s ? s->index.get() : nullptr;
+    }
+
 private:
     struct Slot {
         size_t dim = 0, capacity = 0;
-        std::unique_ptr<L2Space> space;
-        std::unique_ptr<HierarchicalNSW> index;
+        std::unique_ptr<L2Space<float>> space;
+        std::unique_ptr<HierarchicalNSW<float>> index;
     };
     std::mutex lock_;
     std::map<std::string, Slot> table_;
@@ -121,12 +137,12 @@ private:
         return it == table_.end() ? nullptr : &it->second;
     }
     Slot& create(const std::string& key, size_t dim) {
-        Slot& s = table_[key];
+        Slot s;
         s.dim = dim;
         s.capacity = initial_capacity;
-        s.space.reset(new L2Space(dim));
-        s.index.reset(new HierarchicalNSW(s.space.get(), s.capacity, M, ef_construction, 100, false, device));
-        return s;
+        s.space.reset(new L2Space<float>(dim));
+        s.index.reset(new HierarchicalNSW<float>(s.space.get(), s.capacity, M, ef_construction, 100, false, device));  // may throw
+        return table_[key] = std::move(s);
     }
     static bool parse_int(const std::string& t, long long& v) {
         errno = 0;
@@ -140,7 +156,7 @@ private:
             errno = 0;
             char* e = nullptr;
             const float f = std::strtof(args[i].c_str(), &e);
-            if (errno != 0 || e == args[i].c_str() || *e != '\0' || !(f == f)) return false;
+            if (errno != 0 || e == args[i].c_str() || *e != '\0' || !std::isfinite(f)) return false;
             v.push_back(f);
         }
         return !v.empty();

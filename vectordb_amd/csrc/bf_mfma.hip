@@ -964,9 +964,6 @@ __global__ __launch_bounds__(64) void bf_rerank(RerankArgs a) {
 bool gemm8_selected(bool bf16, uint32_t) { return bf16; }
 
 void launch_gemm(bool bf16, dim3 grid, hipStream_t stream, const GemmArgs& g) {
-    // diagnostics of the bf16 loop, tools/exp_gemm.py and tools/abl_gemm.sh
-    static const bool stamps = std::getenv("VDB_GEMM_STAMPS") != nullptr;
-    static const int abl = std::getenv("VDB_GEMM_ABL") ? std::atoi(std::getenv("VDB_GEMM_ABL")) : 0;
     auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), 0, stream, g); };
     if (!bf16) {
         go(bf_gemm_filter);
@@ -974,10 +971,21 @@ void launch_gemm(bool bf16, dim3 grid, hipStream_t stream, const GemmArgs& g) {
                            g.count, g.entries, g.cap);
         return;
     }
+#ifdef VDB_DIAG
+    // Diagnostic builds only (make DIAG=1; tools/exp_gemm.py, tools/abl_gemm.sh): the stamped loop and the ablated loops, which
+    // return WRONG answers.  The shipped library holds none of them and reads no environment variable here.
+    static const bool stamps = std::getenv("VDB_GEMM_STAMPS") != nullptr;
+    static const int abl = std::getenv("VDB_GEMM_ABL") ? std::atoi(std::getenv("VDB_GEMM_ABL")) : 0;
     if (stamps) go(bf_gemm8_filter<true, 0>);
     else if (abl == 1) go(bf_gemm8_filter<false, 1>);
+    else if (abl == 8) go(bf_gemm8_filter<false, 8>);
     else if (abl == 9) go(bf_gemm8_filter<false, 9>);
+    else if (abl == 16) go(bf_gemm8_filter<false, 16>);
+    else if (abl == 17) go(bf_gemm8_filter<false, 17>);
     else go(bf_gemm8_filter<false, 0>);
+#else
+    go(bf_gemm8_filter<false, 0>);
+#endif
     hipLaunchKernelGGL(bf_scatter_recs, dim3(kGemmBlocks * 8), dim3(256), 0, stream, reinterpret_cast<const GemmRec*>(g.hit_key), g.hit_count,
                        g.off, g.tauhat, g.row_hi, g.nq, g.count, g.entries, g.cap);
 }

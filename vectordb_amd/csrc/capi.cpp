@@ -127,7 +127,7 @@ struct SearchScratch {
         if (report) (void)hipHostFree(report);
         if (report_done) (void)hipEventDestroy(report_done);
     }
-    size_t redo_cap = 0;
+    size_t redo_cap = 0;  // queries per call that `redo` holds: kRedoHeader + 2 * redo_cap words
     uint32_t bitmap_words = 0;
 };
 
@@ -448,11 +448,14 @@ SearchScratch& scratch_for(vdb_index* idx, hipStream_t stream, size_t nq) {
     auto& slot = idx->scratch[stream];
     if (!slot) slot.reset(new SearchScratch);
     SearchScratch& s = *slot;
-    if (s.redo_cap < nq + 1) {
+    // [header | re-run list: nq words | fail list: nq words] - the fail list (search_device) starts at kRedoHeader + nq
+    // of the CURRENT call, so a call needs kRedoHeader + 2 nq words whatever an earlier, smaller call allocated
+    if (s.redo_cap < nq) {
         // a previous call on this stream may still be using the old buffer
         if (s.redo.p) VDB_HIP(hipStreamSynchronize(stream));
-        s.redo.alloc((nq + kRedoHeader) * 4 * 2);
-        s.redo_cap = (nq + kRedoHeader) * 2 - kRedoHeader;
+        const size_t cap = std::max<size_t>(nq + nq / 2, 64);  // grow by more than asked: fewer reallocations
+        s.redo.alloc((kRedoHeader + 2 * cap) * 4);
+        s.redo_cap = cap;
     }
     const uint32_t tables = (uint32_t)std::min<size_t>(std::max<size_t>((nq + 31) / 32 * 32, kSpillTablesMin), kSpillTablesMax);
     if (s.spill_tables < tables) {
@@ -731,6 +734,22 @@ int vdb_index_add(vdb_index* idx, const float* vec, uint64_t label, int level) {
     return guarded([&] {
         if (!idx || !vec) throw std::invalid_argument("null argument");
         idx->host->add(vec, label, level);
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_index_add_point(vdb_index* idx, const float* vec, uint64_t label, int replace_deleted) {
+    return guarded([&] {
+        if (!idx || !vec) throw std::invalid_argument("null argument");
+        idx->host->add_point(vec, label, replace_deleted != 0);
+        return (int)VDB_OK;
+    });
+}
+
+int vdb_index_set_reuse_deleted(vdb_index* idx, int on) {
+    return guarded([&] {
+        if (!idx) throw std::invalid_argument("null index");
+        idx->host->set_reuse_deleted(on != 0);
         return (int)VDB_OK;
     });
 }
@@ -1103,6 +1122,14 @@ int vdb_index_unmark_delete(vdb_index* idx, uint64_t label) {
     });
 }
 
+int vdb_index_get_data_by_label(const vdb_index* idx, uint64_t label, float* out) {
+    return guarded([&] {
+        if (!idx || !out) throw std::invalid_argument("null argument");
+        idx->host->get_data_by_label(label, out);
+        return (int)VDB_OK;
+    });
+}
+
 int vdb_index_resize(vdb_index* idx, size_t new_capacity) {
     return guarded([&] {
         if (!idx) throw std::invalid_argument("null index");
@@ -1113,7 +1140,12 @@ int vdb_index_resize(vdb_index* idx, size_t new_capacity) {
 
 int vdb_index_check_integrity(const vdb_index* idx, int* min_inbound, int* max_inbound) {
     if (!idx) return -1;
-    return idx->host->check_integrity(min_inbound, max_inbound);
+    int verdict = -1;
+    const int rc = guarded([&] {  // (throws for an index whose rows are not on the host: no exception crosses the C ABI)
+        verdict = idx->host->check_integrity(min_inbound, max_inbound);
+        return (int)VDB_OK;
+    });
+    return rc == VDB_OK ? verdict : -1;
 }
 
 size_t vdb_index_capacity(const vdb_index* idx) { return idx ? idx->host->capacity : 0; }
@@ -1130,11 +1162,19 @@ int vdb_index_level_of(const vdb_index* idx, uint32_t id) {
 }
 int vdb_index_links(const vdb_index* idx, uint32_t id, int level, uint32_t* out, int cap) {
     if (!idx || id >= idx->host->count || level < 0 || level > idx->host->levels[id]) return -1;
-    if (level == 0) idx->host->require_rows("get_linklist0");
-    const uint32_t* list = idx->host->list_at(id, level);
-    const int n = (int)HostIndex::list_count(list);
-    for (int i = 0; i < n && i < cap; ++i) out[i] = list[1 + i];
-    return n;
+    if (cap > 0 && !out) return -1;
+    if (level == 0 && !idx->host->rows_resident) {  // opened by vdb_index_load_to_device: layer 0 lives on the device only
+        set_error(VDB_ERR_RUNTIME, "get_linklist0: the level-0 rows of this index are not held on the host (vdb_index_load_to_device)");
+        return -1;
+    }
+    int n = -1;
+    const int rc = guarded([&] {  // no exception crosses the C ABI
+        const uint32_t* list = idx->host->list_at(id, level);
+        n = (int)HostIndex::list_count(list);
+        for (int i = 0; i < n && i < cap; ++i) out[i] = list[1 + i];
+        return (int)VDB_OK;
+    });
+    return rc == VDB_OK ? n : -1;
 }
 
 int vdb_index_to_device(vdb_index* idx, int device) {
@@ -1482,7 +1522,8 @@ const RcclApi& rccl_api() {
             if (h) break;
         }
         if (!h) {
-            a.error = std::string("RCCL is not loadable (librccl.so.1): ") + (dlerror() ? dlerror() : "?");
+            const char* why = dlerror();  // (a second call returns NULL: the first one clears the message)
+            a.error = std::string("RCCL is not loadable (librccl.so.1): ") + (why ? why : "?");
             return a;
         }
         auto bind = [&](auto& fn, const char* sym) {

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <fstream>
 #include <limits>
+#include <set>
 #include <stdexcept>
 #include <thread>
 #include <unordered_set>
@@ -185,8 +186,9 @@ void HostIndex::prune_heuristic(std::vector<DistId>& pool, size_t m, BuildScratc
     pool.assign(keep.begin(), keep.end());
 }
 
-// mutuallyConnectNewElement, :392-498 (insert path, updateFlag = false).  Consumes sc.top.
-uint32_t HostIndex::connect(uint32_t id, int level, BuildScratch& sc) {
+// mutuallyConnectNewElement, :392-498; `update` = its updateFlag (an insert holds the element's own lock
+// already, an update takes it for the rewrite of the element's list, :411-414).  Consumes sc.top.
+uint32_t HostIndex::connect(uint32_t id, int level, BuildScratch& sc, bool update) {
     const size_t max_m = level ? maxM : maxM0;
     auto& sel = sc.work;
     sel.assign(sc.top.begin(), sc.top.end());
@@ -197,12 +199,20 @@ uint32_t HostIndex::connect(uint32_t id, int level, BuildScratch& sc) {
     if (sel.empty()) throw std::runtime_error("no neighbour candidates for a new element");
     const uint32_t next_closest = sel.back().id;
     {
+        SpinLock& own = node_locks_[id];
+        if (update) own.lock();
+        struct Unlock {
+            SpinLock* l;
+            ~Unlock() {
+                if (l) l->unlock();
+            }
+        } unlock_own{update ? &own : nullptr};
         uint32_t* mine = list_at(id, level);
-        if (*mine) throw std::runtime_error("The newly inserted element should have a blank neighbor list");
+        if (*mine && !update) throw std::runtime_error("The newly inserted element should have a blank neighbor list");
         set_list_count(mine, (unsigned)sel.size());
         uint32_t* data = mine + 1;
         for (size_t i = 0; i < sel.size(); ++i) {
-            if (data[i]) throw std::runtime_error("Possible memory corruption");
+            if (data[i] && !update) throw std::runtime_error("Possible memory corruption");
             if (level > levels[sel[i].id]) throw std::runtime_error("Trying to make a link on a non-existent level");
             data[i] = sel[i].id;
         }
@@ -222,7 +232,11 @@ uint32_t HostIndex::connect(uint32_t id, int level, BuildScratch& sc) {
             throw std::runtime_error("Trying to make a link on a non-existent level");
         }
         uint32_t* data = other + 1;
-        if (n_other < max_m) {
+        bool present = false;  // :455-463: an updated element may be linked from there already
+        if (update)
+            for (size_t j = 0; j < n_other && !present; ++j) present = data[j] == id;
+        if (present) {
+        } else if (n_other < max_m) {
             data[n_other] = id;
             set_list_count(other, (unsigned)(n_other + 1));
         } else {
@@ -317,10 +331,188 @@ void HostIndex::insert(uint32_t id, const float* v, int level, BuildScratch& sc)
     }
 }
 
-void HostIndex::add(const float* v, uint64_t label, int level) {
+void HostIndex::add(const float* v, uint64_t label, int level) {  // addPoint(data, label, level), :994-1104
     require_rows("addPoint");
+    uint32_t existing = 0xFFFFFFFFu;
+    {
+        std::unique_lock<std::mutex> g(label_lock_);
+        auto it = label_map_.find(label);
+        if (it != label_map_.end()) existing = it->second;
+    }
+    if (existing != 0xFFFFFFFFu) {  // :1001-1016: the element is updated instead of created
+        if (reuse_deleted_ && is_deleted(existing))
+            throw std::runtime_error("Can't use addPoint to update deleted elements if replacement of deleted elements is enabled.");
+        if (is_deleted(existing)) set_deleted_flag(existing, false);
+        BuildScratch sc;
+        update_point(existing, v, sc);
+        ++version;
+        return;
+    }
     uint64_t l = label;
     add_batch(v, &l, 1, 1, level);
+}
+
+void HostIndex::set_reuse_deleted(bool on) {
+    require_rows("reuse_deleted");
+    std::unique_lock<std::mutex> g(deleted_lock_);
+    reuse_deleted_ = on;
+    deleted_elements_.clear();
+    if (on) {  // as the load constructor does, :672-677
+        const size_t n = count;
+        for (size_t i = 0; i < n; ++i)
+            if (is_deleted((uint32_t)i)) deleted_elements_.insert((uint32_t)i);
+    }
+}
+
+void HostIndex::set_deleted_flag(uint32_t id, bool del) {  // markDeletedInternal / unmarkDeletedInternal, :728-782
+    unsigned char* flag = ((unsigned char*)list0(id)) + 2;
+    if (del) {
+        if (*flag & 0x01) throw std::runtime_error("The requested to delete element is already deleted");
+        *flag |= 0x01;
+        deleted += 1;
+    } else {
+        if (!(*flag & 0x01)) throw std::runtime_error("The requested to undelete element is not deleted");
+        *flag &= (unsigned char)~0x01;
+        deleted -= 1;
+    }
+    if (reuse_deleted_) {
+        std::unique_lock<std::mutex> g(deleted_lock_);
+        if (del) deleted_elements_.insert(id);
+        else deleted_elements_.erase(id);
+    }
+}
+
+void HostIndex::add_point(const float* v, uint64_t label, bool replace_deleted) {  // :804-842
+    require_rows("addPoint");
+    if (!reuse_deleted_ && replace_deleted) throw std::runtime_error("Replacement of deleted elements is disabled in constructor");
+    if (!replace_deleted) return add(v, label, -1);
+    uint32_t vacant = 0xFFFFFFFFu;
+    {
+        std::unique_lock<std::mutex> g(deleted_lock_);
+        if (!deleted_elements_.empty()) {
+            vacant = *deleted_elements_.begin();
+            deleted_elements_.erase(deleted_elements_.begin());
+        }
+    }
+    if (vacant == 0xFFFFFFFFu) return add(v, label, -1);
+    const uint64_t old_label = label_of(vacant);
+    std::memcpy(row(vacant) + label_off, &label, 8);  // setExternalLabel
+    {
+        std::unique_lock<std::mutex> g(label_lock_);
+        label_map_.erase(old_label);
+        label_map_[label] = vacant;
+    }
+    set_deleted_flag(vacant, false);
+    BuildScratch sc;
+    update_point(vacant, v, sc);
+    ++version;
+}
+
+// updatePoint(dataPoint, internalId, updateNeighborProbability = 1.0), :844-913.  The reference walks two
+// unordered_sets; here the candidates are met in ascending id order, which together with the (dist, id) heap order
+// decides which of several candidates at exactly the same distance survive `distance < top` (:888) - the order the
+// neighbours are taken in does not matter, each list is rebuilt from distances alone.  (update_rng_, :865: with
+// probability 1.0 no draw can skip a neighbour, so none is made.)
+void HostIndex::update_point(uint32_t id, const float* v, BuildScratch& sc) {
+    sc.ensure(capacity);
+    std::memcpy(row(id) + data_off, v, data_size);
+    const int max_level_copy = max_level;
+    const uint32_t entry_copy = entry;
+    if (entry_copy == id && count == 1) return;
+    const int elem_level = levels[id];
+    auto connections = [&](uint32_t node, int layer) {  // getConnectionsWithLock, :983-991
+        SpinLock& lk = node_locks_[node];
+        lk.lock();
+        const uint32_t* list = list_at(node, layer);
+        std::vector<uint32_t> out(list + 1, list + 1 + list_count(list));
+        lk.unlock();
+        return out;
+    };
+    std::vector<DistId> pool;
+    for (int layer = 0; layer <= elem_level; ++layer) {
+        const std::vector<uint32_t> one_hop = connections(id, layer);
+        if (one_hop.empty()) continue;
+        std::set<uint32_t> s_cand, s_neigh;
+        s_cand.insert(id);
+        for (uint32_t a : one_hop) {
+            s_cand.insert(a);
+            s_neigh.insert(a);
+            for (uint32_t b : connections(a, layer)) s_cand.insert(b);
+        }
+        for (uint32_t neigh : s_neigh) {
+            const size_t size = s_cand.count(neigh) ? s_cand.size() - 1 : s_cand.size();
+            const size_t keep = std::min(ef_construction, size);
+            pool.clear();  // max-heap under result_less: the `keep` closest candidates of `neigh`
+            for (uint32_t c : s_cand) {
+                if (c == neigh) continue;
+                const float d = dist_(vec(neigh), vec(c), dim);
+                if (pool.size() < keep) {
+                    pool.push_back({d, c});
+                    std::push_heap(pool.begin(), pool.end(), result_less);
+                } else if (keep != 0 && d < pool.front().d) {
+                    std::pop_heap(pool.begin(), pool.end(), result_less);
+                    pool.back() = {d, c};
+                    std::push_heap(pool.begin(), pool.end(), result_less);
+                }
+            }
+            prune_heuristic(pool, layer == 0 ? maxM0 : maxM, sc);
+            std::sort(pool.begin(), pool.end(), [](const DistId& a, const DistId& b) { return result_less(b, a); });
+            SpinLock& lk = node_locks_[neigh];
+            lk.lock();
+            uint32_t* list = list_at(neigh, layer);
+            set_list_count(list, (unsigned)pool.size());  // (entries behind the new count keep their old bytes, as :902-907)
+            for (size_t i = 0; i < pool.size(); ++i) list[1 + i] = pool[i].id;
+            lk.unlock();
+        }
+    }
+    repair_connections(id, v, entry_copy, elem_level, max_level_copy, sc);
+}
+
+// repairConnectionsForUpdate, :924-980
+void HostIndex::repair_connections(uint32_t id, const float* v, uint32_t entry_copy, int elem_level, int max_level_copy,
+                                   BuildScratch& sc) {
+    uint32_t cur = entry_copy;
+    if (elem_level < max_level_copy) {
+        float cur_d = dist_(v, vec(cur), dim);
+        for (int lv = max_level_copy; lv > elem_level; --lv) {
+            bool moved = true;
+            while (moved) {
+                moved = false;
+                SpinLock& lk = node_locks_[cur];
+                lk.lock();
+                const uint32_t* list = list_at(cur, lv);
+                const unsigned n = list_count(list);
+                uint32_t best = cur;
+                for (unsigned i = 0; i < n; ++i) {
+                    const float d = dist_(v, vec(list[1 + i]), dim);
+                    if (d < cur_d) {
+                        cur_d = d;
+                        best = list[1 + i];
+                        moved = true;
+                    }
+                }
+                lk.unlock();
+                cur = best;
+            }
+        }
+    }
+    if (elem_level > max_level_copy) throw std::runtime_error("Level of item to be updated cannot be bigger than max level");
+    for (int lv = elem_level; lv >= 0; --lv) {
+        beam_search_layer(cur, v, lv, sc);
+        auto& top = sc.top;  // drop the element itself (:962-967)
+        top.erase(std::remove_if(top.begin(), top.end(), [&](const DistId& e) { return e.id == id; }), top.end());
+        std::make_heap(top.begin(), top.end(), result_less);
+        if (top.empty()) continue;
+        if (is_deleted(entry_copy)) {  // :970-975
+            top.push_back({dist_(v, vec(entry_copy), dim), entry_copy});
+            std::push_heap(top.begin(), top.end(), result_less);
+            if (top.size() > ef_construction) {
+                std::pop_heap(top.begin(), top.end(), result_less);
+                top.pop_back();
+            }
+        }
+        cur = connect(id, lv, sc, /*update=*/true);
+    }
 }
 
 // Ids, levels and rows of n new elements, assigned in input order exactly as n sequential addPoint
@@ -335,7 +527,7 @@ size_t HostIndex::append_unlinked(const float* vecs, const uint64_t* labels, siz
         for (size_t i = 0; i < n; ++i) {
             const uint64_t l = labels ? labels[i] : (uint64_t)(base + i);
             if (label_map_.count(l) || !fresh.insert(l).second)
-                throw std::runtime_error("label already present: the update path (hnsw_core.hpp:1001-1016) is not implemented");
+                throw std::runtime_error("label already present in a bulk insert (add the point alone to update it: hnsw_core.hpp:1001-1016)");
         }
         for (size_t i = 0; i < n; ++i) label_map_[labels ? labels[i] : (uint64_t)(base + i)] = (uint32_t)(base + i);
     }
@@ -416,6 +608,10 @@ void HostIndex::truncate_to_empty() {
     }
     count = 0;
     deleted = 0;
+    {
+        std::unique_lock<std::mutex> g(deleted_lock_);
+        deleted_elements_.clear();
+    }
     entry = 0xFFFFFFFFu;
     max_level = -1;
     ++version;
@@ -423,6 +619,19 @@ void HostIndex::truncate_to_empty() {
 
 void HostIndex::add_batch(const float* vecs, const uint64_t* labels, size_t n, int n_threads, int forced_level) {
     if (n == 0) return;
+    if (labels && n > 1) {
+        // a label that exists (or comes twice) means an update (:1001-1016): such a batch is n sequential addPoint calls
+        bool updates = false;
+        {
+            std::unique_lock<std::mutex> g(label_lock_);
+            std::unordered_set<uint64_t> fresh;
+            for (size_t i = 0; i < n && !updates; ++i) updates = label_map_.count(labels[i]) != 0 || !fresh.insert(labels[i]).second;
+        }
+        if (updates) {
+            for (size_t i = 0; i < n; ++i) add(vecs + i * dim, labels[i], forced_level);
+            return;
+        }
+    }
     const size_t base = append_unlinked(vecs, labels, n, forced_level);
     std::vector<uint32_t> ids(n);
     for (size_t i = 0; i < n; ++i) ids[i] = (uint32_t)(base + i);
@@ -557,17 +766,16 @@ void HostIndex::mark_delete(uint64_t label, bool undo) {  // :709-782
         if (it == label_map_.end()) throw std::runtime_error("Label not found");
         id = it->second;
     }
-    unsigned char* flag = ((unsigned char*)list0(id)) + 2;
-    if (!undo) {
-        if (*flag & 0x01) throw std::runtime_error("The requested to delete element is already deleted");
-        *flag |= 0x01;
-        deleted += 1;
-    } else {
-        if (!(*flag & 0x01)) throw std::runtime_error("The requested to undelete element is not deleted");
-        *flag &= (unsigned char)~0x01;
-        deleted -= 1;
-    }
+    set_deleted_flag(id, !undo);
     ++version;
+}
+
+void HostIndex::get_data_by_label(uint64_t label, float* out) {  // :683-703
+    require_rows("getDataByLabel");
+    std::unique_lock<std::mutex> g(label_lock_);
+    auto it = label_map_.find(label);
+    if (it == label_map_.end() || is_deleted(it->second)) throw std::runtime_error("Label not found");
+    std::memcpy(out, vec(it->second), data_size);
 }
 
 void HostIndex::resize(size_t new_cap) {  // :500-522

@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -94,6 +95,12 @@ public:
     HostIndex& operator=(const HostIndex&) = delete;
 
     void add(const float* vec, uint64_t label, int level);
+    // addPoint(datapoint, label, replace_deleted), hnsw_core.hpp:804-842: a label that exists is UPDATED in place
+    // (updatePoint :844-913, repairConnectionsForUpdate :924-980); with replace_deleted a deleted element's place is reused.
+    void add_point(const float* vec, uint64_t label, bool replace_deleted);
+    // the constructors' reuse_deleted flag (:114, :123): deleted elements are remembered as vacant places
+    void set_reuse_deleted(bool on);
+    bool reuse_deleted() const { return reuse_deleted_; }
     void add_batch(const float* vecs, const uint64_t* labels, size_t n, int n_threads, int forced_level = -1);
     // the two halves of add_batch, for the device builder (hnsw_build.hip): store, then link a subset on the host
     size_t append_unlinked(const float* vecs, const uint64_t* labels, size_t n, int forced_level = -1,
@@ -112,6 +119,7 @@ public:
     void set_rng_state(uint64_t s) { rng_.s = s; }
     void save(const std::string& path) const;
     void mark_delete(uint64_t label, bool undo);
+    void get_data_by_label(uint64_t label, float* out);  // getDataByLabel, :683-703
     void resize(size_t new_capacity);
     int check_integrity(int* min_in, int* max_in) const;
 
@@ -145,6 +153,13 @@ private:
     dist_fn dist_ = nullptr;
 
     bool layer0_as_upper_ = false;
+    bool reuse_deleted_ = false;             // :103
+    std::mutex deleted_lock_;                // :104
+    std::set<uint32_t> deleted_elements_;    // :105 (ordered: the vacant place taken first is the smallest id - the
+                                             // reference takes begin() of an unordered_set, i.e. an unspecified one)
+    void update_point(uint32_t id, const float* vec, BuildScratch& sc);
+    void repair_connections(uint32_t id, const float* vec, uint32_t entry_copy, int elem_level, int max_level_copy, BuildScratch& sc);
+    void set_deleted_flag(uint32_t id, bool deleted);
     void init_layout();
     void alloc_storage(size_t cap, bool with_rows = true);
     void release();
@@ -152,7 +167,7 @@ private:
     void insert(uint32_t id, const float* vec, int level, BuildScratch& sc);
     void beam_search_layer(uint32_t ep, const float* q, int layer, BuildScratch& sc);
     void prune_heuristic(std::vector<DistId>& pool, size_t m, BuildScratch& sc);
-    uint32_t connect(uint32_t id, int level, BuildScratch& sc);
+    uint32_t connect(uint32_t id, int level, BuildScratch& sc, bool update = false);
     void refresh_dist() { dist_ = pick_distance(metric, sum_order); }
 
 public:

@@ -67,8 +67,6 @@ class HierarchicalNSW:
                  stream_to_device: int | None = None):
         """``location``: the load constructor.  With ``stream_to_device`` = a device ordinal the file's level-0 block is
         streamed to that GPU without a host copy (vdb_index_load_to_device): the index searches, but cannot be edited or saved."""
-        if reuse_deleted:
-            raise VdbError(_lib.VDB_ERR_UNSUPPORTED, "reuse_deleted is not implemented")
         self._l = _lib.lib()
         self.space = space
         self._h = C.c_void_p()
@@ -80,6 +78,8 @@ class HierarchicalNSW:
             check(self._l.vdb_index_create(C.byref(self._h), space.metric, space.dim, capacity, M, ef_construction,
                                            random_seed))
         self._device = stream_to_device if location is not None else None
+        if reuse_deleted:  # hnsw_core.hpp:114, :123
+            check(self._l.vdb_index_set_reuse_deleted(self._h, 1))
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -89,10 +89,10 @@ class HierarchicalNSW:
 
     # ---- building (host, reference algorithm) -------------------------------------
     def addPoint(self, datapoint, label: int, replace_deleted: bool = False) -> None:
-        if replace_deleted:
-            raise VdbError(_lib.VDB_ERR_RUNTIME, "Replacement of deleted elements is disabled in constructor")
+        """hnsw_core.hpp:804-842: inserts, updates the element when the label exists (:1001-1016), or - with
+        ``replace_deleted`` - takes the place of a deleted element (:815-841)."""
         v = _as_f32(datapoint, self.space.dim)
-        check(self._l.vdb_index_add(self._h, v.ctypes.data_as(_f32p), int(label), -1))
+        check(self._l.vdb_index_add_point(self._h, v.ctypes.data_as(_f32p), int(label), int(bool(replace_deleted))))
 
     def add_items(self, vecs, labels=None, n_threads: int = 1) -> None:
         v = _as_f32(vecs, self.space.dim)
@@ -133,6 +133,11 @@ class HierarchicalNSW:
 
     def unmarkDelete(self, label: int) -> None:
         check(self._l.vdb_index_unmark_delete(self._h, label))
+
+    def getDataByLabel(self, label: int) -> np.ndarray:  # hnsw_core.hpp:683-703
+        out = np.empty(self.space.dim, np.float32)
+        check(self._l.vdb_index_get_data_by_label(self._h, int(label), out.ctypes.data_as(_f32p)))
+        return out
 
     def resizeIndex(self, new_capacity: int) -> None:
         check(self._l.vdb_index_resize(self._h, new_capacity))
