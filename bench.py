@@ -119,6 +119,40 @@ class Dist:
             self.d.destroy_process_group()
 
 
+def launch_ranks(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child process and
+    print the JSON line its rank 0 prints (everything else the children write to stdout goes to stderr)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("launching " + " ".join(cmd))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        try:
+            if out.startswith("{") and "metric" in json.loads(out):
+                line = out
+                continue
+        except ValueError:
+            pass
+        print(out, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        log("the ranks exited without printing a result line")
+        rc = 1
+    return rc
+
+
 def timed_sharded_steps(sharding, hs, shared_q, k, steps, warmup, dd, comm=None):
     """W + K sharded steps.  The timed step is ONE call of the C-ABI entry point
     (vdb_sharded_search_batch_device: shard search + grouped ncclAllGather + merge on one stream) when an
@@ -173,7 +207,15 @@ def main() -> None:
     ap.add_argument("--build", choices=("host", "device"), default="host",
                     help="graph builder: host = the reference algorithm on the host cores (default: the graph the headline\n"
                          "number is quoted on), device = vdb_index_add_batch_device (DESIGN.md 4.3)")
+    ap.add_argument("--no-c4-block", action="store_true", help="skip the configs[3] block (10M x 96, 8 shards on one GPU) of the default line")
+    ap.add_argument("--no-c5-block", action="store_true", help="skip the configs[4] block (one 12.5M-row shard of the 8-way split, k=100) of the default line")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # A plain `python bench.py --gpus N`: this process becomes the launcher.  It starts the N ranks as CHILD
+        # processes (torch.distributed.run, one per GPU) before anything here has touched the GPU - no torch import,
+        # no HIP call - relays rank 0's JSON line and exits with the children's status.
+        raise SystemExit(launch_ranks(args.gpus))
 
     import torch
 
@@ -181,11 +223,15 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: pass --gpus {world}, or start bench.py without a launcher "
+                         f"(python bench.py --gpus N starts its own ranks)")
     # rehearsal on a one-GPU box only: VDB_BENCH_REHEARSAL=1 puts every rank on device 0 over gloo
     rehearsal = os.environ.get("VDB_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    elif torch.cuda.device_count() < world:   # (counting devices does not initialise the GPU)
+        raise SystemExit(f"--gpus {world} but {torch.cuda.device_count()} GPU(s) visible "
+                         f"(VDB_BENCH_REHEARSAL=1 rehearses the ranks on one GPU over gloo)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dd = Dist(world, rehearsal, dev)
@@ -333,6 +379,40 @@ def run_hnsw(args, dd, rank, local_rank, world, dev, cores, threads):
         h.setefSearch(chosen)
         log("larger ef, same batch: " + ", ".join(f"ef {e}: {v['ms_per_batch']} ms ({v['roofline']['frac']:.2f} of HBM peak)" for e, v in by_ef.items()))
 
+    # ---- the non-bare path (hnsw_core.hpp:1141-1148) on the same graph and batch: a random filter that keeps a half / a tenth
+    # of the elements, ef 64, against exact filtered brute force (outside the timed region; not `value`)
+    filtered = None
+    if rank == 0 and world == 1 and not args.no_ef_block:
+        filtered = {}
+        h.setefSearch(64)
+        for keep in (0.5, 0.1):
+            ok = np.random.default_rng(17).random(n) < keep
+            bits = torch.frombuffer(bytearray(h.filter_bitmap(ok)), dtype=torch.int32).to(dev)
+            _, lab_f, st_f = h.search_batch(dq, k, stats=True, filter=bits)
+            bf2 = vi.BruteforceSearch(vi.L2Space(dim), int(ok.sum()))   # exact: brute force over the allowed rows only
+            bf2.add_items(base[ok], np.nonzero(ok)[0].astype(np.uint64))
+            bf2.to_device(local_rank)
+            _, truth_f = bf2.search_batch(dq[:1000].contiguous(), k)
+            torch.cuda.synchronize()
+            del bf2
+            rec_f = datasets.recall_at_k(lab_f[:1000].cpu().numpy().view(np.uint64), truth_f.cpu().numpy().view(np.uint64))
+            for _ in range(3):
+                h.search_batch(dq, k, filter=bits)
+                torch.cuda.synchronize()
+            ev_f = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+            for a, b in ev_f:
+                a.record()
+                h.search_batch(dq, k, filter=bits)
+                b.record()
+            torch.cuda.synchronize()
+            st_f = st_f.cpu().numpy().view(np.uint32).astype(np.int64)
+            ms_f = float(np.mean([a.elapsed_time(b) for a, b in ev_f]))
+            filtered[f"keeps_{keep}"] = {"ef": 64, "ms_per_batch": round(ms_f, 3), "queries_per_s": round(args.nq / ms_f * 1e3, 1),
+                                         "recall_at_10_vs_exact_filtered": round(rec_f, 4), "mean_ndis": round(float(st_f[:, 0].mean()), 1),
+                                         "mean_hops": round(float(st_f[:, 1].mean()), 1)}
+        h.setefSearch(chosen)
+        log("filtered, ef 64: " + ", ".join(f"{name}: {v['ms_per_batch']} ms (recall {v['recall_at_10_vs_exact_filtered']})" for name, v in filtered.items()))
+
     # ---- sharded variant (north star): base split over ranks + RCCL all-gather + merge --
     sharded = None
     if world > 1 and not args.no_sharded:
@@ -394,10 +474,22 @@ def run_hnsw(args, dd, rank, local_rank, world, dev, cores, threads):
                "gpu_ids_and_distances_equal_oracle_on_whole_batch": same}
         del o
 
-    bruteforce = None
-    if rank == 0 and world == 1 and not args.no_bruteforce:
+    bruteforce = c4_block = c5_block = None
+    if rank == 0 and world == 1:
         del h, base
-        bruteforce = run_bruteforce(args, dev, cores, threads, standalone=False)
+        # further blocks of the one line; a failure in one of them is reported in its place and never costs the headline
+        def guarded_block(fn, *a):
+            try:
+                return fn(*a)
+            except Exception as e:  # noqa: BLE001
+                log(f"{fn.__name__} failed: {e!r}")
+                return {"error": repr(e)}
+        if not args.no_bruteforce:
+            bruteforce = guarded_block(run_bruteforce, args, dev, cores, threads, False)
+        if not args.no_c4_block:
+            c4_block = guarded_block(run_c4_one_gpu, args, dev, threads)
+        if not args.no_c5_block:
+            c5_block = guarded_block(run_c5_shard_one_gpu, args, dev, threads)
 
     if rank != 0:
         return None
@@ -442,11 +534,177 @@ def run_hnsw(args, dd, rank, local_rank, world, dev, cores, threads):
     }
     if by_ef is not None:
         out["traversal_by_ef"] = by_ef
+    if filtered is not None:
+        out["filtered_search"] = filtered
     if sharded is not None:
         out["sharded"] = sharded
     if bruteforce is not None:
         out["bruteforce"] = bruteforce
+    if c4_block is not None:
+        out["c4_one_gpu"] = c4_block
+    if c5_block is not None:
+        out["c5_shard_one_gpu"] = c5_block
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# configs[3] / configs[4] on ONE GPU, as blocks of the default line
+# ------------------------------------------------------------------------------------------------
+
+def _traversal_roofline(st, dim, M, nq, k, ms):
+    st = st.cpu().numpy().view(np.uint32).astype(np.int64)
+    alg = int((st[:, 0] * 4 * dim + st[:, 1] * 4 * (2 * M + 1) + st[:, 2] * 4 * (M + 1)).sum() + nq * (4 * dim + k * 12))
+    return alg, st
+
+
+def run_c4_one_gpu(args, dev, threads):
+    """BASELINE.json configs[3] at FULL size on one GPU: 10M x 96, rows L2-normalised, metric 1 - <a,b>, 8 shards x 1.25M
+    contiguous rows, each an independent graph (seed 100 + s, labels = global row ids) built on the device; the 10 000
+    queries are searched on the eight shards one after the other and merged by merge_topk - the multi-GPU pipeline
+    of sharding.py with the all-gather replaced by "the lists are already here" (on eight GPUs each rank runs one of the
+    eight searches).  ef = the smallest of (32, 48, 64) with recall@10 >= 0.95 against exact brute force over all rows."""
+    import torch
+
+    from vectordb_amd import datasets, sharding
+    from vectordb_amd import index as vi
+    n, dim, G, nq, k, M = 10_000_000, 96, 8, args.nq, 10, 16
+    law = datasets.ClusteredLaw(dim, latent=32, normalize=True)
+    t0 = time.time()
+    base = law.sample(n, seed=1)
+    q = law.sample(nq, seed=2)
+    dq = torch.from_numpy(q).to(dev)
+    t_data = time.time() - t0
+    t0 = time.time()
+    bf = vi.BruteforceSearch(vi.InnerProductSpace(dim), n)
+    bf.add_items(base)
+    bf.to_device(dev.index)
+    _, truth = bf.search_batch(dq, k)
+    torch.cuda.synchronize()
+    truth = truth.cpu().numpy().view(np.uint64)
+    del bf
+    t_truth = time.time() - t0
+    t0 = time.time()
+    shards = [sharding.build_shard(base, G, s, vi.IP, M, 200, n_threads=threads, device_build=dev.index) for s in range(G)]
+    build_s = time.time() - t0
+    del base
+    log(f"c4: data {t_data:.1f}s, exact ground truth {t_truth:.1f}s, {G} shards on the device in {build_s:.1f}s")
+
+    def step(stats=False):
+        res = [h.search_batch(dq, k, stats=stats) for h in shards]
+        md, ml = vi.merge_topk(torch.stack([r[0] for r in res]), torch.stack([r[1] for r in res]))
+        return md, ml, ([r[2] for r in res] if stats else None)
+
+    sweep, ef = {}, None
+    for e in (32, 48, 64):
+        for h in shards:
+            h.setefSearch(e)
+        _, ml, _ = step()
+        torch.cuda.synchronize()
+        sweep[e] = round(datasets.recall_at_k(ml.cpu().numpy().view(np.uint64), truth), 4)
+        ef = e
+        if sweep[e] >= 0.95:
+            break
+    _, ml, sts = step(stats=True)
+    torch.cuda.synchronize()
+    alg = sum(_traversal_roofline(st, dim, M, nq, k, 0)[0] for st in sts)
+    for _ in range(3):
+        step()
+        torch.cuda.synchronize()
+    steps = 10
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    for e3 in ev:
+        e3[0].record()
+        res = [h.search_batch(dq, k) for h in shards]
+        e3[1].record()
+        vi.merge_topk(torch.stack([r[0] for r in res]), torch.stack([r[1] for r in res]))
+        e3[2].record()
+    torch.cuda.synchronize()
+    ms_search = float(np.mean([a.elapsed_time(b) for a, b, _ in ev]))
+    ms_merge = float(np.mean([b.elapsed_time(c) for _, b, c in ev]))
+    ms = ms_search + ms_merge
+    gbs = alg / ms_search / 1e6
+    log(f"c4: ef sweep {sweep} -> ef={ef}; {ms:.2f} ms per batch ({ms_search:.2f} search of {G} shards + {ms_merge:.2f} merge), "
+        f"{gbs:.0f} GB/s algorithmic")
+    return {"workload": f"BASELINE.json configs[3]: HNSW {n}x{dim} rows L2-normalised, metric 1 - <a,b>, {G} shards x {n // G} rows, "
+                        f"M={M}, efConstruction=200, {nq}-query batch, k={k}; all {G} shards on ONE GPU, searched one after the other",
+            "ef": ef, "ef_sweep_recall_at_10": sweep, "recall_at_10": sweep[ef], "ms_per_batch": round(ms, 3),
+            "ms_split": {"search_all_shards": round(ms_search, 3), "merge_topk": round(ms_merge, 3)},
+            "queries_per_s_one_gpu": round(nq / ms * 1e3, 1), "shard_build_seconds_device": round(build_s, 1),
+            "shard_build_points_per_s": round(n / build_s, 0),
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "traffic": None, "kernel": f"hnsw_search_kernel ({G} launches per batch)", "kernel_ms": round(ms_search, 3),
+                         "algorithmic_bytes_per_launch": alg}}
+
+
+def run_c5_shard_one_gpu(args, dev, threads):
+    """BASELINE.json configs[4], the work of ONE of its eight ranks at full size: rows [0, 12.5M) of the 100M x 128 set
+    as one device-built sub-graph (8.2 GB image), the 10 000-query batch, k = 100, ef = the smallest of (100, 128, 200,
+    300) whose recall@100 against exact brute force over the shard is >= 0.95, then merge_topk over the one list (the
+    rank's share of the exchange step).  The whole set on one GPU (65.6 GB image, 92 s build) is tools/exp_c5.py."""
+    import torch
+
+    from vectordb_amd import datasets
+    from vectordb_amd import index as vi
+    n, dim, nq, k, M = 12_500_000, 128, args.nq, 100, 16
+    law = datasets.ClusteredLaw(dim, latent=32)
+    t0 = time.time()
+    base = law.sample(n, seed=1000)
+    q = law.sample(nq, seed=2)
+    dq = torch.from_numpy(q).to(dev)
+    t_data = time.time() - t0
+    t0 = time.time()
+    bf = vi.BruteforceSearch(vi.L2Space(dim), n)
+    bf.add_items(base)
+    bf.to_device(dev.index)
+    _, truth = bf.search_batch(dq[:2000].contiguous(), k)
+    torch.cuda.synchronize()
+    truth = truth.cpu().numpy().view(np.uint64)
+    del bf
+    t_truth = time.time() - t0
+    t0 = time.time()
+    h = vi.HierarchicalNSW(vi.L2Space(dim), n, M, 200, 100)
+    h.add_items_device(base, n_threads=threads, device=dev.index)
+    build_s = time.time() - t0
+    del base
+    log(f"c5 shard: data {t_data:.1f}s, exact ground truth (2000 queries) {t_truth:.1f}s, graph on the device in {build_s:.1f}s "
+        f"({h.device_bytes() / 1e9:.2f} GB)")
+    by_ef, chosen = {}, None
+    for ef in (100, 128, 200, 300):
+        h.setefSearch(ef)
+        _, lab, st = h.search_batch(dq, k, stats=True)
+        torch.cuda.synchronize()
+        rec = datasets.recall_at_k(lab[:2000].cpu().numpy().view(np.uint64), truth)
+        alg, stn = _traversal_roofline(st, dim, M, nq, k, 0)
+        for _ in range(3):
+            h.search_batch(dq, k)
+            torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for a, b in ev:
+            a.record()
+            h.search_batch(dq, k)
+            b.record()
+        torch.cuda.synchronize()
+        ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        by_ef[str(ef)] = {"recall_at_100": round(rec, 4), "ms_per_batch": round(ms, 3), "queries_per_s": round(nq / ms * 1e3, 1),
+                          "mean_ndis": round(float(stn[:, 0].mean()), 1), "mean_hops": round(float(stn[:, 1].mean()), 1),
+                          "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg}}
+        if rec >= 0.95:
+            chosen = ef
+            break
+    d, l = h.search_batch(dq, k)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    for a, b in ev:
+        a.record()
+        vi.merge_topk(d.unsqueeze(0), l.unsqueeze(0))
+        b.record()
+    torch.cuda.synchronize()
+    log("c5 shard: " + ", ".join(f"ef {e}: recall@100 {v['recall_at_100']}, {v['ms_per_batch']} ms ({v['roofline']['frac']:.2f} of HBM peak)" for e, v in by_ef.items()))
+    return {"workload": f"BASELINE.json configs[4], one rank's share at 8 GPUs: HNSW {n}x{dim} L2 (rows [0, {n}) of 100M), M={M}, "
+                        f"efConstruction=200, graph built on the device, {nq}-query batch, k={k}",
+            "ef_with_recall_at_100_ge_0.95": chosen, "by_ef": by_ef, "build_seconds_device": round(build_s, 1),
+            "build_points_per_s": round(n / build_s, 0), "device_image_gb": round(h.device_bytes() / 1e9, 2),
+            "merge_topk_ms_one_list": round(float(np.mean([a.elapsed_time(b) for a, b in ev])), 3)}
 
 
 # ------------------------------------------------------------------------------------------------
