@@ -50,7 +50,7 @@ def test_device_build_recall_and_integrity(orc, tmp_path, monkeypatch, n, dim, m
     assert [dev.level_of(i) for i in range(0, n, 97)] == [host.level_of(i) for i in range(0, n, 97)]
     assert dev.max_level == host.max_level and dev.level_of(dev.entry) == dev.max_level
     rc, mn, mx = dev.checkIntegrity()
-    assert rc in (0, 4), rc          # 4 = some node without inbound link: legal after pruning (as on the host build)
+    assert rc == 0 and mn >= 1, (rc, mn)   # every element has an inbound link (hnsw_core.hpp:1238; the builder's last pass sees to it)
     r_dev = _recall(dev, x, q, 10, 64, labels)
     print(f"recall@10 ef=64: host build {r_host:.4f}, device build {r_dev:.4f}")
     assert r_dev >= r_host - 0.02
@@ -100,7 +100,7 @@ def test_device_build_wide_lists(orc, tmp_path, monkeypatch, M):
     r_host = _recall(host, x, q, 10, 48)
     dev = vi.HierarchicalNSW(vi.L2Space(dim), n, M, 100, 100)
     dev.add_items_device(x, n_threads=8)
-    assert dev.checkIntegrity()[0] in (0, 4)
+    assert dev.checkIntegrity()[0] == 0
     sizes = [len(dev.links(i, 0)) for i in range(0, n, 53)]
     assert max(sizes) <= 2 * M and max(sizes) > 32 and np.mean(sizes) > M / 2     # lists beyond one lane's worth exist
     r_dev = _recall(dev, x, q, 10, 48)
@@ -132,3 +132,65 @@ def test_device_build_of_a_handful_at_small_M(orc, tmp_path, n):
     o = orc.OracleHNSW.load(path, vi.L2, dim, mode=orc.TREE64)
     o.set_ef(16)
     assert_same_results((d, l), o.search(x, min(n, 3)))
+
+
+def _device_built_bytes(tmp_path, name, n=6000, dim=16, M=8, efc=48, seed=81):
+    x = datasets.clustered(n, dim, seed)
+    h = vi.HierarchicalNSW(vi.L2Space(dim), n, M, efc, 100)
+    h.add_items_device(x, n_threads=1, device=0)     # one host thread: the host-built top of the recursion has an order
+    path = str(tmp_path / name)
+    h.saveIndex(path)
+    with open(path, "rb") as f:
+        return f.read(), h
+
+
+def test_device_build_is_deterministic_and_matches_its_golden(tmp_path, monkeypatch):
+    """with ONE host thread (the only unordered step is the multi-threaded host build of the small
+    top sub-graph) two device builds of the same data write the same bytes - pairs are emitted at fixed positions, the
+    radix sort is stable, one wave owns a neighbour's list, the orphan pass runs in id order - so a device-built graph
+    can have a golden: tests/golden/device_build_golden.json holds the SHA-256 of this build's saved file (made by
+    tests/golden/make_device_build_golden.py on an MI355X)."""
+    import hashlib
+    import json
+    monkeypatch.setenv("VDB_BUILD_HOST_BASE", "64")
+    a, h = _device_built_bytes(tmp_path, "a.bin")
+    b, _ = _device_built_bytes(tmp_path, "b.bin")
+    assert a == b
+    assert h.checkIntegrity()[0] == 0
+    gp = os.path.join(os.path.dirname(__file__), "golden", "device_build_golden.json")
+    with open(gp) as f:
+        gold = json.load(f)
+    assert hashlib.sha256(a).hexdigest() == gold["sha256"], "the device builder's output changed: regenerate the golden if that is intended"
+
+
+def test_device_build_leaves_no_orphans_on_clustered_shards():
+    """200 000 clustered rows at M = 16 (a shard of tests/test_large_configs_gpu.py): before the orphan pass a handful of
+    elements per build ended without an inbound link (checkIntegrity 4); the host build of the same rows has none."""
+    law = datasets.ClusteredLaw(128, latent=32)
+    x = law.sample(200_000, seed=1)
+    h = vi.HierarchicalNSW(vi.L2Space(128), len(x), 16, 200, 100)
+    h.add_items_device(x, n_threads=16, device=0)
+    rc, mn, mx = h.checkIntegrity()
+    assert rc == 0 and mn >= 1
+
+
+@pytest.mark.parametrize("dim,efc,metric,seed", [(128, 100, vi.IP, 1), (96, 40, vi.L2, 2), (96, 100, vi.L2, 3), (96, 100, vi.IP, 4),
+                                                 (128, 100, vi.IP, 5), (32, 40, vi.L2, 6)])
+def test_device_build_small_M_recall(dim, efc, metric, seed):
+    """the shapes of the six fuzz cases that fell 0.021-0.030 below the host build (all M = 4 on
+    2 000 rows, profiles/r2/fuzz_build.log), three data seeds each: within 0.02 of the host build's recall@10 at ef 64."""
+    n, M = 2000, 4
+    space = vi.L2Space(dim) if metric == vi.L2 else vi.InnerProductSpace(dim)
+    worst = 0.0
+    for s in range(3):
+        x = datasets.clustered(n, dim, 900 + 10 * seed + s, normalize=(metric == vi.IP))
+        q = datasets.clustered(300, dim, 950 + 10 * seed + s, normalize=(metric == vi.IP))
+        host = vi.HierarchicalNSW(space, n, M, efc, 100)
+        host.add_items(x, n_threads=8)
+        host.to_device(0)
+        dev = vi.HierarchicalNSW(space, n, M, efc, 100)
+        dev.add_items_device(x, n_threads=8, device=0)
+        r_host, r_dev = _recall(host, x, q, 10, 64), _recall(dev, x, q, 10, 64)
+        worst = max(worst, r_host - r_dev)
+        print(f"dim {dim} efc {efc} metric {metric} seed {s}: host {r_host:.4f} device {r_dev:.4f}")
+    assert worst <= 0.02, worst

@@ -849,6 +849,8 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
     }
     std::string err;
     size_t done = 0, round = 0;
+    size_t batch_div = M < 8 ? 16 : 4;
+    if (const char* e = std::getenv("VDB_BUILD_BATCH_DIV")) batch_div = (size_t)std::max(1l, std::atol(e));
     while (done < dev_ids.size()) {
         // as in search_device: an observation is read only behind the event of the round that wrote it
         bool arm_report = true;
@@ -871,7 +873,9 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
         }
         work.report = arm_report ? sc->report : nullptr;
         // a batch is searched against the graph WITHOUT its own members: keep it a fraction of it
-        const size_t nb = std::min<size_t>(std::min<size_t>(max_batch, std::max<size_t>(linked / 4, 8)), dev_ids.size() - done);
+        // (a quarter at M >= 8; a sixteenth below: with four links per element a batch that large cost 0.02-0.03 of
+        // recall@10 on 2 000-row sets, profiles/r2/fuzz_build.log)
+        const size_t nb = std::min<size_t>(std::min<size_t>(max_batch, std::max<size_t>(linked / batch_div, 8)), dev_ids.size() - done);
         const uint32_t* bid = (const uint32_t*)ids.p + done;
         if (launch_gather_rows(g0.vecs, g0.vstride, g0.dim, bid, (uint32_t)nb, (float*)q.p, stream) != 0)
             throw DeviceError("gather kernel launch failed");
@@ -903,6 +907,12 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
     sc->report[0] = sc->report[1] = 0;
     sc->report_pending = false;
     tr.lap("device rounds (layer 0)", dev_ids.size());
+    {
+        uint32_t found = 0, fixed = 0;
+        if (build_repair_orphans(links0, (uint32_t)total, g0.l0stride, maxM0, stream, &found, &fixed, &err) != 0) throw DeviceError(err);
+        if (tr.on) std::fprintf(stderr, "[vdb build] elements without an inbound link on layer 0: %u, given one: %u\n", found, fixed);
+        tr.lap("orphan repair", found);
+    }
     // the device lists are the graph now: write them back in the reference's layout (:259-261, :283-285)
     const uint32_t ls = g0.l0stride;
     const size_t chunk = 1 << 16;

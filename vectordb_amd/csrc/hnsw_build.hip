@@ -22,9 +22,11 @@
 // built by the host builder first, with the reference algorithm.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>  // rocPRIM's headers call memset without including it
 #include <string>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -215,6 +217,73 @@ __global__ __launch_bounds__(64) void build_reverse_kernel(ReverseArgs a) {
     if ((uint32_t)lane < ls) a.links0[(size_t)nb * ls + lane] = (uint32_t)lane < nk ? v : kNoId;
 }
 
+// ---- orphans.  The reference's checkIntegrity (:1235-1241) demands an inbound link for every element.  The heuristic
+// can prune the last one away - in the reference too, but a batch makes it likelier (up to 32 newcomers compete for
+// one full list in a single pass; 200 000 clustered rows at M = 16: a handful of elements per build, none in the
+// host build).  After the last round every element nobody links to on layer 0 is given one link FROM the nearest
+// element of its own list that can take it: appended where the list has room, else in place of the first entry that
+// somebody else links to as well (so nothing is orphaned in turn).
+__global__ __launch_bounds__(256) void count_inbound_kernel(const uint32_t* links0, size_t words, uint32_t n, uint32_t* cnt) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) {
+        const uint32_t v = links0[i];
+        if (v < n) atomicAdd(&cnt[v], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void list_orphans_kernel(const uint32_t* cnt, uint32_t n, uint32_t* list, uint32_t cap, uint32_t* n_found) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        if (cnt[i] == 0u) {
+            const uint32_t slot = atomicAdd(n_found, 1u);
+            if (slot < cap) list[slot] = (uint32_t)i;
+        }
+    }
+}
+
+// One wave, the orphans one after the other in ascending id order (the host sorts the list): a repair sees the
+// lists and counts the repairs before it left, and the outcome does not depend on scheduling.
+__global__ __launch_bounds__(64) void repair_orphans_kernel(uint32_t* links0, uint32_t ls, uint32_t maxM0, uint32_t* cnt,
+                                                            const uint32_t* list, uint32_t n_list, uint32_t* n_fixed) {
+    const int lane = lane_id();
+    auto ld = [](const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto st = [](uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    uint32_t fixed = 0;
+#pragma unroll 1
+    for (uint32_t w = 0; w < n_list; ++w) {
+        const uint32_t p = list[w];
+        if (ld(cnt + p) != 0u) continue;
+        const uint32_t mine = (uint32_t)lane < ls ? ld(links0 + (size_t)p * ls + lane) : kNoId;
+        const uint32_t np = (uint32_t)__builtin_popcountll(ballot(mine != kNoId));  // lists are packed to the front
+        bool done = false;
+#pragma unroll 1
+        for (uint32_t j = np; j-- > 0 && !done;) {  // closest last
+            const uint32_t q = readlane(mine, (int)j);
+            const uint32_t theirs = (uint32_t)lane < ls ? ld(links0 + (size_t)q * ls + lane) : kNoId;
+            const uint32_t c = (uint32_t)__builtin_popcountll(ballot(theirs != kNoId));
+            if (c < maxM0) {
+                if (lane == 0) st(links0 + (size_t)q * ls + c, p);
+                done = true;
+            } else {
+                const uint32_t their_cnt = theirs != kNoId ? ld(cnt + theirs) : 0u;
+                const uint64_t spare = ballot(their_cnt >= 2u);
+                if (spare) {
+                    const int e = __builtin_ctzll(spare);
+                    if (lane == e) {
+                        st(cnt + theirs, their_cnt - 1u);
+                        st(links0 + (size_t)q * ls + e, p);
+                    }
+                    done = true;
+                }
+            }
+        }
+        if (done) {
+            if (lane == 0) st(cnt + p, 1u);
+            fixed += 1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    }
+    if (lane == 0) *n_fixed = fixed;
+}
+
 template <int NCH, int GPB>
 void launch_select(const SelectArgs& a, hipStream_t s) {
     if (a.g.metric == 0) hipLaunchKernelGGL((build_select_kernel<NCH, GPB, true>), dim3(a.nb), dim3(64), 0, s, a);
@@ -240,6 +309,57 @@ int launch_gather_rows(const float* d_vecs, uint32_t vstride, uint32_t dim, cons
     if (n == 0) return 0;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, d_vecs, vstride, dim, d_ids, n, d_out);
     return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+int build_repair_orphans(uint32_t* d_links0, uint32_t n, uint32_t l0stride, uint32_t maxM0, hipStream_t stream,
+                         uint32_t* found, uint32_t* fixed, std::string* err) {
+    if (found) *found = 0;
+    if (fixed) *fixed = 0;
+    if (n < 2) return 0;
+    constexpr uint32_t kCap = 1u << 20;
+    uint32_t *cnt = nullptr, *list = nullptr, *hdr = nullptr;
+    auto fail = [&](hipError_t e) {
+        if (err) *err = std::string("device graph build (orphan repair): ") + hipGetErrorString(e);
+        (void)hipFree(cnt);
+        (void)hipFree(list);
+        (void)hipFree(hdr);
+        return 3;
+    };
+    hipError_t e = hipMalloc((void**)&cnt, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&list, (size_t)kCap * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&hdr, 8);
+    if (e == hipSuccess) e = hipMemsetAsync(cnt, 0, (size_t)n * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(hdr, 0, 8, stream);
+    if (e != hipSuccess) return fail(e);
+    const size_t words = (size_t)n * l0stride;
+    const uint32_t blocks = (uint32_t)std::min<size_t>((words + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL(count_inbound_kernel, dim3(blocks), dim3(256), 0, stream, d_links0, words, n, cnt);
+    hipLaunchKernelGGL(list_orphans_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 256 * 64)), dim3(256), 0, stream, cnt, n, list, kCap, hdr);
+    uint32_t h[2] = {0, 0};
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h, hdr, 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return fail(e);
+    const uint32_t n_list = h[0] < kCap ? h[0] : kCap;
+    if (found) *found = h[0];
+    if (n_list) {
+        std::vector<uint32_t> ids(n_list);
+        e = hipMemcpy(ids.data(), list, (size_t)n_list * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return fail(e);
+        std::sort(ids.begin(), ids.end());  // (the list was filled through a counter: its order is the waves' arrival)
+        e = hipMemcpy(list, ids.data(), (size_t)n_list * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail(e);
+        hipLaunchKernelGGL(repair_orphans_kernel, dim3(1), dim3(64), 0, stream, d_links0, l0stride, maxM0, cnt, list, n_list, hdr + 1);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(h, hdr, 8, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return fail(e);
+        if (fixed) *fixed = h[1];
+    }
+    (void)hipFree(cnt);
+    (void)hipFree(list);
+    (void)hipFree(hdr);
+    return 0;
 }
 
 int launch_build_round(const DevGraph& g, uint32_t* d_links0, const uint64_t* d_cand_label, const float* d_cand_dist,

@@ -106,6 +106,12 @@ int launch_build_round(const DevGraph& g, uint32_t* d_links0, const uint64_t* d_
                        const uint32_t* d_new_ids, uint32_t nb, uint32_t efc, uint32_t M, uint32_t maxM0, const BuildWork& w,
                        hipStream_t stream, std::string* err);
 
+// After the last round: every element without an inbound link on layer 0 gets one from the nearest element of its own
+// list that can take it (the reference's checkIntegrity demands one, hnsw_core.hpp:1235-1241).  Synchronises `stream`.
+// found / fixed: elements without an inbound link before / given one.
+int build_repair_orphans(uint32_t* d_links0, uint32_t n, uint32_t l0stride, uint32_t maxM0, hipStream_t stream,
+                         uint32_t* found, uint32_t* fixed, std::string* err);
+
 // ---- brute force (bf_search.hip) ---------------------------------------------------------
 constexpr uint32_t kBfCap = 4096;   // candidate entries per query between two compactions
 constexpr uint32_t kBfMaxK = 1024;
