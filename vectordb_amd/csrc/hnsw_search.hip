@@ -1114,7 +1114,10 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
             int n = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hnsw_search_kernel<NCH, GPB, R, 0, true, FILT>, 64, 1024) != hipSuccess || n <= 0)
                 return 8u;
-            return (uint32_t)(n > 16 ? 16 : n);  // (a body under 100 registers could have 20: an 8 KB table is too small)
+            // (a body under 100 registers could have 20: measured in round 3, profiles/r3/residency_and_batch_size.txt -
+            // no gain at ef <= 100, where a loaded GPU runs at the HBM rate, and the 6 KB table that is left is outgrown
+            // by half the searches from ef 128 on)
+            return (uint32_t)(n > 16 ? 16 : n);
         }();
         size_t share = ((size_t)160 * 1024 / per_cu) / 1024 * 1024;
         if (lds_small < share) lds_small = share;
@@ -1274,11 +1277,16 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
         return 3;
     }
     const uint32_t nch = (g.vstride + 63u) / 64u;
+#ifdef VDB_ONLY_DIM128  // (make FAST=1: a quick build for kernel experiments on 65-128-dimensional data; never shipped)
+    if (nch != 2) return unsupported("this is a FAST=1 build: dim 65-128 only");
+    return launch_r<2, 8>(a, stream, err);
+#else
     if (nch <= 1) return launch_r<1, 8>(a, stream, err);
     if (nch <= 2) return launch_r<2, 8>(a, stream, err);
     if (nch <= 4) return launch_r<4, 4>(a, stream, err);
     if (nch <= 8) return launch_r<8, 2>(a, stream, err);
     return launch_r<16, 1>(a, stream, err);
+#endif
 }
 
 }  // namespace vdb
