@@ -374,6 +374,7 @@ def run_hnsw(args, dd, rank, local_rank, world, dev, cores, threads):
             by_ef[str(ef)] = {"ms_per_batch": round(ms_e, 4), "queries_per_s": round(args.nq / ms_e * 1e3, 1),
                               "recall_at_10": round(datasets.recall_at_k(lab_e.cpu().numpy().view(np.uint64), gt), 4),
                               "mean_ndis": round(float(st_e[:, 0].mean()), 1), "mean_hops": round(float(st_e[:, 1].mean()), 1),
+                              "batch_ns_per_expanded_node": round(ms_e * 1e6 / float(st_e[:, 1].sum()), 3),
                               "roofline": {"bound": "hbm", "achieved": round(bytes_e / ms_e / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": round(bytes_e / ms_e / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": bytes_e}}
         h.setefSearch(chosen)
@@ -396,7 +397,7 @@ def run_hnsw(args, dd, rank, local_rank, world, dev, cores, threads):
             torch.cuda.synchronize()
             del bf2
             rec_f = datasets.recall_at_k(lab_f[:1000].cpu().numpy().view(np.uint64), truth_f.cpu().numpy().view(np.uint64))
-            for _ in range(3):
+            for _ in range(6):   # (the launches' reports size the candidate buffer and the visited set: up to five steps)
                 h.search_batch(dq, k, filter=bits)
                 torch.cuda.synchronize()
             ev_f = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
@@ -409,7 +410,10 @@ def run_hnsw(args, dd, rank, local_rank, world, dev, cores, threads):
             ms_f = float(np.mean([a.elapsed_time(b) for a, b in ev_f]))
             filtered[f"keeps_{keep}"] = {"ef": 64, "ms_per_batch": round(ms_f, 3), "queries_per_s": round(args.nq / ms_f * 1e3, 1),
                                          "recall_at_10_vs_exact_filtered": round(rec_f, 4), "mean_ndis": round(float(st_f[:, 0].mean()), 1),
-                                         "mean_hops": round(float(st_f[:, 1].mean()), 1)}
+                                         "mean_hops": round(float(st_f[:, 1].mean()), 1),
+                                         # what a filter costs beyond the hops it adds (a filter that keeps a tenth makes the
+                                         # search expand ten times the nodes: that part is the algorithm's, hnsw_core.hpp:316)
+                                         "batch_ns_per_expanded_node": round(ms_f * 1e6 / float(st_f[:, 1].sum()), 3)}
         h.setefSearch(chosen)
         log("filtered, ef 64: " + ", ".join(f"{name}: {v['ms_per_batch']} ms (recall {v['recall_at_10_vs_exact_filtered']})" for name, v in filtered.items()))
 

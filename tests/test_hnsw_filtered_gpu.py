@@ -85,9 +85,10 @@ def test_filter_functor(orc, mod, keep, ef):
 
 @pytest.mark.parametrize("mod,ef", [(2, 64), (4, 40), (10, 32), (3, 128)])
 def test_repeated_filtered_launches_adapt_and_stay_exact(orc, mod, ef):
-    """The first level of a filtered search holds 128 keys at ef <= 64 (256 at ef <= 128): a filter that keeps 1/mod of
-    the elements needs about ef * mod.  The first launch re-runs the overflowing queries in the large configuration, the
-    report of that launch doubles the key registers of the next ones at this ef (twice, if need be): every launch equals
+    """The first level of a filtered search keeps the candidates that are not allowed in a buffer (64 keys in registers,
+    256 in LDS to begin with): a filter that keeps 1/mod of the elements needs about ef * (mod - 1) live ones.  Host
+    arrays: the verdicts are counted and the first launch sizes the buffer from them; whatever still overflows is re-run
+    in the large configuration and its report doubles the buffer of the next launches at this ef: every launch equals
     the oracle, whichever kernels answered it."""
     n, dim = 20000, 24
     x = datasets.clustered(n, dim, 71)
@@ -198,3 +199,46 @@ def test_device_against_committed_golden():
     for ef, k in ((16, 5), (64, 10)):
         check("nonbare_del", ef, k, None)
         check("nonbare_delmod3", ef, k, lambda lab: lab % 3 == 1)
+
+
+@pytest.mark.parametrize("mod,ef", [(8, 64), (12, 100), (25, 40)])
+def test_filter_as_device_bitmap_adapts_from_reports(orc, mod, ef):
+    """The same through a DEVICE bitmap (vdb_search_batch_device_filtered): the library cannot count the verdicts, so the
+    first launch runs with the smallest candidate buffer, most queries overflow it and are answered by the large
+    configuration (and the heap kernel behind it); the reports then grow the buffer launch by launch, and the visited
+    set moves to HBM when the LDS table is outgrown.  Every launch equals the oracle bit for bit."""
+    import torch
+    n, dim = 30000, 24
+    x = datasets.clustered(n, dim, 91)
+    q = datasets.clustered(512, dim, 92)
+    h, o = build_pair(orc, x, n_threads=4)
+    h.to_device(0)
+    h.setefSearch(ef)
+    o.set_ef(ef)
+    r = o.search(q, 10, filter_mod=mod, filter_keep=2)
+    bitmap = torch.frombuffer(bytearray(h.filter_bitmap(lambda lab: lab % mod == 2)), dtype=torch.int32).cuda()
+    dq = torch.from_numpy(q).cuda()
+    for _ in range(6):
+        d, l, st = h.search_batch(dq, 10, stats=True, filter=bitmap)
+        torch.cuda.synchronize()
+        assert_same_results((d.cpu().numpy(), l.cpu().numpy().view(np.uint64)), r, st.cpu().numpy().view(np.uint32))
+
+
+def test_many_equal_distances_among_rejected_candidates(orc):
+    """Blocks of identical rows that the filter rejects: hundreds of candidates at exactly the same distance go through
+    the candidate buffer (refills move the smallest (distance, id) first, ties included) - ids and counters equal the
+    oracle's."""
+    rng = np.random.default_rng(17)
+    base = datasets.clustered(40, 16, 93)
+    x = np.repeat(base, 150, axis=0)               # 6 000 rows, 150 copies of each of 40 vectors
+    x = x[rng.permutation(len(x))].copy()
+    q = datasets.clustered(100, 16, 94)
+    h, o = build_pair(orc, x, M=8, efc=60, n_threads=4)
+    h.to_device(0)
+    for ef, mod in ((20, 7), (64, 31), (128, 5)):
+        h.setefSearch(ef)
+        o.set_ef(ef)
+        r = o.search(q, 10, filter_mod=mod, filter_keep=1)
+        for _ in range(3):
+            d, l, st = h.search_batch(q, 10, stats=True, filter=lambda lab: lab % mod == 1)
+            assert_same_results((d, l), r, st)

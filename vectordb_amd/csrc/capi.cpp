@@ -119,6 +119,7 @@ struct SearchScratch {
     uint32_t* report = nullptr;
     uint32_t report_ef = 0;
     bool report_filtered = false;
+    uint32_t report_level = 0;  // the filt_level that launch ran with
     // recorded behind the launch that writes `report`; the words are read (and the next observation
     // armed) only once it has completed, so what a launch adapts to never depends on timing
     hipEvent_t report_done = nullptr;
@@ -162,7 +163,7 @@ struct vdb_index {
     DevBuf live;  // bit i = element i is not deleted; allocated only when the upload saw deleted elements
     std::map<uint32_t, uint32_t> hbits_bias;  // per ef: extra log2 of the visited-set size (guarded by scratch_lock)
     std::set<uint32_t> spill_ef;              // the ef values at which a launch had queries outgrow the LDS table (same lock)
-    std::map<uint32_t, uint32_t> filt_level;  // per ef, filtered searches: steps up in key registers of the first level (same lock)
+    std::map<uint32_t, uint32_t> filt_level;  // per ef, filtered searches: doublings of the first level's candidate buffer (same lock)
     int spill_mode = spill_mode_from_env();   // -1 adaptive, 0 never, 1 always (read once, at creation)
     std::mutex scratch_lock;
     std::map<hipStream_t, std::unique_ptr<SearchScratch>> scratch;
@@ -493,9 +494,10 @@ struct EpsilonStop {
 
 // searchKnn over a batch; d_filter = nullable device bitmap over internal ids (1 = passes the filter).
 // stop != nullptr: searchStopConditionClosest instead - the non-bare layer-0 search with ef = k = max_num_candidates.
+// filter_accepts: how many elements the caller's filter accepts, when the caller knows (host bitmaps); SIZE_MAX = unknown
 int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, const uint32_t* d_filter, float* d_out_dist,
                   uint64_t* d_out_label, uint32_t* d_out_stats, hipStream_t stream, uint32_t** fail_word,
-                  const EpsilonStop* stop = nullptr) {
+                  const EpsilonStop* stop = nullptr, size_t filter_accepts = SIZE_MAX) {
     require_search_ready(idx);
     if (stop) {
         if (!(stop->epsilon == stop->epsilon)) throw std::invalid_argument("epsilon is NaN");
@@ -551,16 +553,23 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
         if (hipEventQuery(s.report_done) == hipSuccess) {
             // (a query whose key array overflowed says nothing about the visited table)
             const uint32_t keys = s.report[2], redone = s.report[0] - std::min(s.report[0], keys), of = s.report[1];
+            if (std::getenv("VDB_TRACE_SEARCH"))
+                std::fprintf(stderr, "[vdb search] report of the launch at ef %u: %u of %u queries outgrew the visited table, %u the key array / candidate buffer\n",
+                             s.report_ef, redone, of, keys);
             if (of != 0 && s.report_ef != 0) {
                 if (redone != 0) idx->spill_ef.insert(s.report_ef);
                 uint32_t& b = idx->hbits_bias[s.report_ef];
                 b = next_hbits_bias(b, redone, of);
-                // filtered searches: the first level's key array holds the ef results AND the live candidates outside
-                // them, about ef / selectivity keys; when more than 2 % of a launch outgrew it the next filtered launches
-                // at this ef start with twice the key registers (sticky; 2 -> 4 -> 8)
-                if (s.report_filtered && (uint64_t)keys * 50u > of) {
+                // filtered searches: the first level keeps the candidates that are not allowed in a buffer in LDS (about
+                // ef (1 - s) / s live keys at selectivity s, plus the ones the shrinking bound has left behind); when more
+                // than 0.2 % of a launch outgrew it the next filtered launches at this ef get twice the buffer (sticky;
+                // 256 -> ... -> 4096 keys beside the 64 in registers)
+                // (0.2 %, not the 2 % of the visited table: an overflow here is a re-run by the large configuration's few waves)
+                // (ANY overflow up to 2 048 keys: however few they are, the queries that overflow are re-run behind the
+                // launch by the large configuration and take a whole search's latency there)
+                if (s.report_filtered && keys != 0 && (s.report_level + 2u < kFiltLevels || (uint64_t)keys * 500u > of)) {
                     uint32_t& lv = idx->filt_level[s.report_ef];
-                    if (lv < 2) lv += 1;
+                    lv = std::min(std::max(lv, s.report_level) + 1u, kFiltLevels - 1u);
                 }
             }
             s.report[0] = s.report[1] = s.report[2] = 0;
@@ -587,7 +596,12 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
     work.bitmaps = (uint32_t*)s.bitmaps.p;
     work.bitmap_words = s.bitmap_words;
     work.large_blocks = s.large_blocks;
-    if (ef > 124 && !allow) {
+    {
+        auto it = idx->hbits_bias.find((uint32_t)ef);
+        work.hbits_bias = it == idx->hbits_bias.end() ? 0u : it->second;
+    }
+    // visited sets in HBM: bare searches at large ef, filtered ones once launches at this ef reported the LDS table outgrown
+    if ((ef > 124 && !allow) || (allow && work.hbits_bias >= 1)) {
         if (!s.ghash.p) s.ghash.alloc(((size_t)kGlobalHashBlocks << kGlobalHashBits) * 4);
         work.ghash = (uint32_t*)s.ghash.p;
     }
@@ -608,20 +622,23 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
         work.fail_list = work.redo + kRedoHeader + nq;  // the second half of the work list's buffer (scratch_for)
     }
     work.report = arm_report ? s.report : nullptr;
-    {
-        auto it = idx->hbits_bias.find((uint32_t)ef);
-        work.hbits_bias = it == idx->hbits_bias.end() ? 0u : it->second;
-    }
     if (allow) {
         auto it = idx->filt_level.find((uint32_t)ef);
         work.filt_level = it == idx->filt_level.end() ? 0u : it->second;
-        // What the host knows ahead of any report: with a fraction f of the elements deleted the array holds about
-        // ef / (1 - f) live keys (a filter on top of that only adds to it).
+        // What the host knows ahead of any report: when a fraction r of the elements is rejected (deleted, or refused by a
+        // filter whose verdicts the caller counted) the buffer holds about ef r / (1 - r) live keys; half as much again
+        // leaves room for the ones the shrinking bound has left behind (a sweep drops them when the buffer is full).
         const size_t n = idx->graph.n, dead = std::min<size_t>(idx->host->deleted, n);
-        if (n != 0 && dead != 0 && dead < n) {
-            const double need = 1.25 * (double)ef * (double)n / (double)(n - dead);
-            uint32_t cap = ef <= 64 ? 128u : ef <= 128 ? 256u : 512u, lv = 0;
-            while (lv < 2 && cap < 512u && (double)cap < need) cap *= 2, lv += 1;
+        size_t rejected = dead;
+        if (filter_accepts != SIZE_MAX && d_filter) {
+            // (deleted elements the filter accepts are rejected too: assume the two are independent)
+            const size_t acc = std::min(filter_accepts, n);
+            rejected = n - (size_t)((double)acc * (double)(n - dead) / (double)std::max<size_t>(n, 1));
+        }
+        if (n != 0 && rejected != 0 && rejected < n) {
+            const double need = 1.5 * (double)ef * (double)rejected / (double)(n - rejected);
+            uint32_t cap = 256u + 64u, lv = 0;
+            while (lv + 1 < kFiltLevels && (double)cap < need) cap = (cap - 64u) * 2u + 64u, lv += 1;
             work.filt_level = std::max(work.filt_level, lv);
         }
     }
@@ -638,9 +655,15 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
     const int rc = launch_hnsw_search(idx->graph, d_queries, (uint32_t)nq, (uint32_t)k, (uint32_t)ef, allow, d_out_dist,
                                       d_out_label, d_out_stats, work, stream, &err);
     if (rc != 0) return set_error(rc, err);
+    static const bool trace = std::getenv("VDB_TRACE_SEARCH") != nullptr;
+    if (trace)
+        std::fprintf(stderr, "[vdb search] nq %zu ef %zu k %zu %s: visited-set bias %u, spill tables %s, candidate-buffer level %u, report %s\n",
+                     nq, ef, k, allow ? "filtered" : "bare", work.hbits_bias, work.spill ? "on" : "off", work.filt_level,
+                     arm_report ? "armed" : "not armed");
     if (arm_report) {
         s.report_ef = (uint32_t)ef;
         s.report_filtered = allow != nullptr;
+        s.report_level = work.filt_level;
         VDB_HIP(hipEventRecord(s.report_done, stream));
         s.report_pending = true;
     }
@@ -668,9 +691,16 @@ int search_host(vdb_index* idx, const float* queries, size_t nq, size_t k, const
         VDB_HIP(hipMemcpy(st.filter.p, filter, words * 4, hipMemcpyHostToDevice));
     }
     uint32_t* fail_word = nullptr;
+    size_t accepts = SIZE_MAX;
+    if (filter) {  // (the verdicts are here anyway: count them, so that the first launch sizes its candidate buffer right)
+        const size_t n = idx->graph.n, words = (n + 31) / 32;
+        accepts = 0;
+        for (size_t w = 0; w + 1 < words; ++w) accepts += (size_t)__builtin_popcount(filter[w]);
+        if (words) accepts += (size_t)__builtin_popcount(filter[words - 1] & (n % 32 ? (1u << (n % 32)) - 1u : 0xFFFFFFFFu));
+    }
     const int rc = search_device(idx, (const float*)st.q.p, nq, k, filter ? (const uint32_t*)st.filter.p : nullptr,
                                  (float*)st.dist.p, (uint64_t*)st.label.p, out_stats ? (uint32_t*)st.stats.p : nullptr, nullptr,
-                                 &fail_word, stop);
+                                 &fail_word, stop, accepts);
     if (rc != VDB_OK) return rc;
     VDB_HIP(hipStreamSynchronize(nullptr));
     uint32_t failed = 0;

@@ -268,6 +268,13 @@ struct KeyArray {
         return found;
     }
 
+    __device__ __forceinline__ uint32_t count_valid() const {  // entries held
+        uint32_t c = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) c += (uint32_t)__builtin_popcountll(ballot(!(hi[r] == kEmptyWord && lo[r] == kEmptyWord)));
+        return c;
+    }
+
     // ---- filtered search (S == 2) only
     // Entry `p` (wave-uniform) leaves the array; everything behind it moves one place forward.
     __device__ __forceinline__ void erase(uint32_t p, int lane) {
@@ -374,6 +381,7 @@ struct SearchArgs {
     uint32_t* report;      // nullable, host-mapped: [0] = queries the fast configuration gave up on, [1] = nq
     uint32_t bitmap_words;
     uint32_t large_blocks; // grid of the large configuration (host side only)
+    uint32_t cb_cap;       // first-level filtered launches: keys the candidate buffer holds (at stage_off; see SPLIT)
     uint32_t eps_ord;      // FILT only: the epsilon stop condition (HnswSearchWork), kEmptyWord = none
     uint32_t eps_min;
     uint32_t* fail_list;   // nullable: queries the large configuration could not answer, for hnsw_search_unbounded_kernel
@@ -396,13 +404,24 @@ struct SearchArgs {
 // registers short; from dim 257 on the query and one row in flight alone take 64-128 registers: bounding those to 128
 // put 13-130 registers into scratch, which round 1 did for R <= 2).
 constexpr bool four_waves(int nch, int gpb, int r, int vis, bool filt) {
-    return !filt && vis != 2 && nch <= 4 && (r <= 2 || (nch * gpb <= 8 && (nch <= 2 || r <= 5)));
+    if (filt) return vis != 2 && nch * gpb <= 8 && nch <= 2 && r <= 4;  // (first-level filtered launches: 8 row chunks in flight)
+    return vis != 2 && nch <= 4 && (r <= 2 || (nch * gpb <= 8 && (nch <= 2 || r <= 5)));
 }
 
 template <int NCH, int GPB, int R, int VIS, bool IS_L2, bool FILT>
 __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) void hnsw_search_kernel(SearchArgs a) {
-    constexpr int S = FILT ? 2 : 1;
+    // SPLIT (round 3): the first-level filtered launches keep two structures, as the reference keeps two heaps.  The key
+    // array holds the ALLOWED nodes only - it is then exactly the bare search's array: results = entries 0..ef-1, bound =
+    // entry ef-1, behind it only keys at the bound's distance - and the admitted nodes that are not allowed, which can
+    // only ever be candidates, wait unsorted in a buffer in LDS (`cb`: 64-bit keys ordered-distance << 32 | id, with the
+    // smallest one known).  The next candidate is the smaller of the array's first open entry and the buffer's minimum;
+    // one taken from the buffer leaves it.  Before, such nodes stood in the array too, which then had to hold about
+    // ef / selectivity keys: a filter that keeps a tenth at ef 64 needs 640 - beyond the 512 keys of eight registers, so
+    // every query went through the large configuration (26 ms per 10 000 queries on the C2 graph, 81 ms at ef 128).
+    // The large configuration (VIS == 2) is the one-array design still (S == 2, 1024 keys), and behind it the heap kernel.
     constexpr bool LARGE = VIS == 2;
+    constexpr bool SPLIT = FILT && !LARGE;
+    constexpr int S = (FILT && !SPLIT) ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = lane_id();
     const DevGraph& g = a.g;
@@ -509,7 +528,127 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
         auto not_allowed = [&](uint32_t id) { return ((a.allow[id >> 5] >> (id & 31u)) & 1u) ^ 1u; };
         uint32_t bound;  // lowerBound once the result set is full, else "no bound"
         bool ep_only_candidate = false;  // (:310 seeds it at "distance" -FLT_MAX: no stop condition fires on it)
-        if constexpr (FILT) {
+        // SPLIT: the candidates that are not allowed (see the head of the kernel), in two parts.  NEAR: at most 64 keys, one
+        // per lane in registers (nr_hi = ordered distance, nr_lo = id; all ones = free lane), unsorted - its minimum is two
+        // wave-wide reductions away.  FAR: the rest, unsorted in LDS.  Every key in FAR has distance >= tx, so a NEAR
+        // minimum below tx is the minimum of both; when NEAR has nothing below tx the smallest keys of FAR are moved over
+        // (far_refill), which also drops FAR's dead keys (beyond the bound).  A key enters NEAR when it lies below tx and
+        // a lane is free, else FAR (and tx comes down to it if it lay below).  Which keys sit where is a matter of speed
+        // only: the candidate taken is always the exact minimum by (distance, id).
+        uint64_t* far = reinterpret_cast<uint64_t*>(lds + a.stage_off);
+        uint32_t nr_hi = kEmptyWord, nr_lo = kEmptyWord;
+        uint32_t far_n = 0, tx = kEmptyWord, tx_step = 1u << 18;
+        auto lds_sync = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        };
+        auto lane_rank = [&](uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+        // the lanes with `f` hand their key to free lanes of NEAR (the caller has made sure there are enough)
+        auto near_put = [&](bool f, uint32_t khi, uint32_t klo) {
+            const uint64_t fm = ballot(f);
+            const uint32_t take = (uint32_t)__builtin_popcountll(fm);
+            const uint32_t r = lane_rank(fm);
+            const uint32_t dest = f ? r : take + ((uint32_t)lane - r);  // a full permutation: no two lanes write one destination
+            const uint32_t ch = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)(f ? khi : kEmptyWord));
+            const uint32_t cl = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)(f ? klo : kEmptyWord));
+            const bool is_free = nr_hi == kEmptyWord;
+            const uint32_t fr = lane_rank(ballot(is_free));
+            const uint32_t gh = bpermute(ch, (int)(fr & 63u)), gl = bpermute(cl, (int)(fr & 63u));
+            if (is_free && fr < take) {
+                nr_hi = gh;
+                nr_lo = gl;
+            }
+        };
+        // One pass over FAR: keys below `ntx` go to NEAR while it has free lanes, dead keys (beyond the bound of a full
+        // result set) go away, the others move up.  Leaves tx = the exclusive lower bound of what stayed.
+        auto far_sweep = [&](uint32_t ntx) {
+            uint32_t w = 0, stay_min = kEmptyWord, moved = 0;
+            for (uint32_t i0 = 0; i0 < far_n; i0 += 64) {
+                const uint32_t i = i0 + (uint32_t)lane;
+                const uint64_t kk = i < far_n ? far[i] : ~0ull;
+                const uint32_t kh = (uint32_t)(kk >> 32);
+                const bool live = i < far_n && !(bound != kEmptyWord && kh > bound);
+                const bool elig = live && kh < ntx;
+                const uint64_t em = ballot(elig);
+                const uint32_t nfree = (uint32_t)__builtin_popcountll(ballot(nr_hi == kEmptyWord));
+                const bool go = elig && lane_rank(em) < nfree;
+                if (em && nfree) near_put(go, kh, (uint32_t)kk);
+                moved += (uint32_t)__builtin_popcountll(ballot(go));
+                const bool keep = live && !go;
+                const uint64_t km = ballot(keep);
+                if (keep && kh < stay_min) stay_min = kh;
+                lds_sync();
+                if (keep) far[w + lane_rank(km)] = kk;
+                w += (uint32_t)__builtin_popcountll(km);
+                lds_sync();
+            }
+            far_n = w;
+            tx = wave_min_u32(stay_min);  // (all ones when nothing stayed)
+            return moved;
+        };
+        // NEAR has nothing below tx and FAR is not empty: bring FAR's smallest keys over
+        auto far_refill = [&]() {
+            if (ballot(nr_hi == kEmptyWord) == 0ull) {  // NEAR is full (of keys at or above tx): back into FAR with it
+                if (far_n + 64u > a.cb_cap) return false;
+                lds_sync();
+                far[far_n + (uint32_t)lane] = ((uint64_t)nr_hi << 32) | nr_lo;
+                lds_sync();
+                far_n += 64;
+                nr_hi = nr_lo = kEmptyWord;
+            }
+            // FAR's smallest key by (distance, id) goes over first, whatever else does: after a refill the minimum of NEAR
+            // is the minimum of both parts (ties in distance included)
+            uint32_t bh = kEmptyWord, bl = kEmptyWord, bp = 0;
+            for (uint32_t i = (uint32_t)lane; i < far_n; i += 64) {
+                const uint64_t kk = far[i];
+                const uint32_t kh = (uint32_t)(kk >> 32), kl = (uint32_t)kk;
+                if (kh < bh || (kh == bh && kl < bl)) {
+                    bh = kh;
+                    bl = kl;
+                    bp = i;
+                }
+            }
+            const uint32_t m = wave_min_u32(bh);
+            const uint32_t ml = wave_min_u32(bh == m ? bl : kEmptyWord);
+            const uint32_t pos = readlane(bp, __builtin_ctzll(ballot(bh == m && bl == ml)));
+            lds_sync();
+            if (lane == 0) far[pos] = far[far_n - 1u];
+            lds_sync();
+            far_n -= 1;
+            if (lane == __builtin_ctzll(ballot(nr_hi == kEmptyWord))) {
+                nr_hi = m;
+                nr_lo = ml;
+            }
+            const uint32_t want = m + 1u + tx_step;
+            const uint32_t moved = far_sweep(want > m ? want : kEmptyWord);  // (no wrap-around)
+            // the window follows what it caught: a quarter to three quarters of NEAR is what a sweep should bring
+            if (moved < 16u && tx_step < (1u << 28)) tx_step <<= 1;
+            else if (moved > 48u && tx_step > 1u) tx_step >>= 1;
+            return true;
+        };
+        // the minimum of NEAR: (distance, id, lane); distance all ones = NEAR is empty
+        auto near_min = [&](uint32_t& mh, uint32_t& ml, int& ml_lane) {
+            mh = wave_min_u32(nr_hi);
+            ml = wave_min_u32(nr_hi == mh ? nr_lo : kEmptyWord);
+            ml_lane = __builtin_ctzll(ballot(nr_hi == mh && nr_lo == ml) | (1ull << 63));
+        };
+        if constexpr (SPLIT) {
+            const uint32_t dis = not_allowed(cur);  // :302-312: an entry point that is not allowed is a candidate only
+            ep_only_candidate = dis != 0;
+            if (dis) {
+                if (lane == 0) {
+                    nr_hi = cur_d;
+                    nr_lo = cur;
+                }
+                bound = kEmptyWord;
+            } else {
+                if (lane == 0) {
+                    arr.hi[0] = cur_d;
+                    arr.lo[0] = cur << 1;
+                }
+                bound = ef > 1 ? kEmptyWord : cur_d;
+            }
+        } else if constexpr (FILT) {
             const uint32_t dis = not_allowed(cur);  // :302-312: an entry point that is not allowed is a candidate only
             ep_only_candidate = dis != 0;
             if (lane == 0) {
@@ -535,6 +674,36 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
         uint32_t cand;
 #pragma unroll 1
         while (true) {
+            if constexpr (SPLIT) {
+                // the next candidate: the array's first open entry or the smallest key that is not allowed, by (distance, id)
+                uint32_t nmh, nml;
+                int nm_lane;
+                near_min(nmh, nml, nm_lane);
+                if (far_n != 0 && nmh >= tx) {
+                    if (!far_refill()) {
+                        overflow = key_overflow = true;
+                        break;
+                    }
+                    near_min(nmh, nml, nm_lane);
+                }
+                uint32_t aid = kNoId, ad = kEmptyWord;
+                const bool has_a = arr.peek_candidate(aid, ad);
+                if (!has_a && nmh == kEmptyWord) break;
+                const bool from_cb = nmh < ad || (nmh == ad && nml < aid);  // (an empty NEAR compares above everything)
+                const uint32_t cd = from_cb ? nmh : ad;
+                // (the epsilon condition's should_stop_search, as below)
+                if (a.eps_ord != kEmptyWord && !(hops0 == 0 && ep_only_candidate) && cd > a.eps_ord) {
+                    const uint32_t held = arr.count_valid();
+                    if ((held < ef ? held : ef) >= a.eps_min) break;
+                }
+                if (bound != kEmptyWord && cd > bound) break;  // :316, `cand > lowerBound && size == ef` (an open entry of the array never is)
+                if (from_cb) {
+                    cand = nml;
+                    if (lane == nm_lane) nr_hi = nr_lo = kEmptyWord;
+                } else {
+                    (void)arr.pop_candidate(lane, cand);
+                }
+            } else {
             if constexpr (FILT) {
                 // BaseSearchStopCondition::should_stop_search of the epsilon condition, asked before the candidate is
                 // taken (searchBaseLayerST with a stop condition): the best open candidate lies beyond
@@ -549,6 +718,7 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
                 }
             }
             if (!(FILT ? arr.pop_candidate_filtered(lane, cand) : arr.pop_candidate(lane, cand))) break;
+            }
             hops0 += 1;
             if (nvis + g.l0stride > vis_limit) {
                 uint32_t more = 0;
@@ -576,7 +746,18 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
             const uint32_t dest = fresh ? rank : m_all + ((uint32_t)lane - rank);
             const uint32_t ids_c = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)(fresh ? nb : kNoId));
             uint32_t peek_d = kEmptyWord;
-            if (arr.peek_candidate(pfa_id, peek_d))
+            bool have_a = arr.peek_candidate(pfa_id, peek_d);
+            if constexpr (SPLIT) {  // (a hint: FAR is not looked at)
+                uint32_t nmh, nml;
+                int nm_lane;
+                near_min(nmh, nml, nm_lane);
+                if (nmh < peek_d || (nmh == peek_d && nmh != kEmptyWord && nml < pfa_id) || (!have_a && nmh != kEmptyWord)) {
+                    pfa_id = nml;
+                    peek_d = nmh;
+                    have_a = true;
+                }
+            }
+            if (have_a)
                 pfa_row = (uint32_t)lane < g.l0stride ? g.links0[(size_t)pfa_id * g.l0stride + lane] : kNoId;
             else
                 pfa_id = kNoId;
@@ -600,6 +781,62 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
                 uint64_t pend = ballot(dord < bound);
                 bool lost = false;  // lane 63: an unexpanded key at the bound's distance fell off the end
                 bool trim_due = false;
+                if constexpr (SPLIT) {
+                    // List order, evolving bound (:339-349).  Only an ALLOWED neighbour's admission moves the bound, so the
+                    // neighbours that are not allowed and stand ahead of the next allowed one go into the buffer together.
+                    const uint64_t nal = ballot(dis != 0u);
+                    while (pend) {
+                        const uint64_t pa = pend & ~nal;
+                        const int al = pa ? __builtin_ctzll(pa) : 64;
+                        const uint64_t seg = pend & nal & (al == 64 ? ~0ull : ((1ull << al) - 1ull));
+                        if (seg) {
+                            const bool in_seg = (seg >> lane) & 1u;
+                            // below tx and a lane free: NEAR; else FAR
+                            const uint64_t em = ballot(in_seg && dord < tx);
+                            const uint32_t nfree = (uint32_t)__builtin_popcountll(ballot(nr_hi == kEmptyWord));
+                            const bool go = in_seg && dord < tx && lane_rank(em) < nfree;
+                            if (em && nfree) near_put(go, dord, ids_part);
+                            const bool to_far = in_seg && !go;
+                            const uint64_t fm = ballot(to_far);
+                            if (fm) {
+                                const uint32_t cnt = (uint32_t)__builtin_popcountll(fm);
+                                if (far_n + cnt > a.cb_cap) {
+                                    (void)far_sweep(tx);  // (drops the dead keys)
+                                    // still more than three quarters full: the next pushes would sweep again and again -
+                                    // the query goes to the large configuration and the host gives the next launches
+                                    // at this ef a larger buffer
+                                    if (far_n + cnt > a.cb_cap - (a.cb_cap >> 2)) {
+                                        overflow = key_overflow = true;
+                                        break;
+                                    }
+                                }
+                                lds_sync();
+                                if (to_far) far[far_n + lane_rank(fm)] = ((uint64_t)dord << 32) | ids_part;
+                                lds_sync();
+                                far_n += cnt;
+                                if (ballot(to_far && dord < tx)) {
+                                    const uint32_t lowest = wave_min_u32(to_far ? dord : kEmptyWord);
+                                    tx = lowest < tx ? lowest : tx;
+                                }
+                            }
+                            pend &= ~seg;
+                        }
+                        if (al < 64) {
+                            pend &= ~(1ull << al);
+                            const uint32_t d = readlane(dord, al);
+                            if (d < bound) {
+                                uint32_t prev_hi, prev_lo;
+                                arr.insert(d, readlane(ids_part, al) << 1, lane, prev_hi, prev_lo);
+                                bound = arr.hi_at(ef - 1);
+                                lost |= lane == 63 && prev_hi != kEmptyWord && prev_hi == bound && (prev_lo & 1u) == 0u;
+                                trim_due = true;
+                                pend &= ballot(dord < bound);
+                            }
+                        }
+                    }
+                    if (trim_due) arr.trim(ef, bound, lane);
+                    pend = 0;
+                }
                 if constexpr (!FILT) {
                     // Two or more neighbours below the bound: one merge instead of one wave-wide shift each.  Every key
                     // learns its place in the merged order by counting (an array entry moves back by the number of new
@@ -675,7 +912,7 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
                         }
                     }
                 }
-                while (pend) {
+                while (!SPLIT && pend) {
                     const int r = __builtin_ctzll(pend);
                     pend &= pend - 1;
                     const uint32_t d = readlane(dord, r);
@@ -749,7 +986,7 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
         // place_of(r, base): this lane's entry of register r among the results (kEmptyWord: not one);
         // `base` runs over the registers in order
         auto place_of = [&](int r, uint32_t& base) -> uint32_t {
-            if constexpr (FILT) {
+            if constexpr (FILT && !SPLIT) {
                 // (filter_results of the epsilon condition: results beyond epsilon are dropped; they are the tail of the order)
                 const bool ok = arr.hi[r] != kEmptyWord && (arr.lo[r] & 2u) == 0u && arr.hi[r] <= a.eps_ord;
                 const uint64_t m = ballot(ok);
@@ -758,7 +995,8 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
                 return ok ? p : kEmptyWord;
             } else {
                 const uint32_t idx = (uint32_t)(r * 64 + lane);
-                const bool ok = idx < ef && !(arr.hi[r] == kEmptyWord && arr.lo[r] == kEmptyWord);
+                bool ok = idx < ef && !(arr.hi[r] == kEmptyWord && arr.lo[r] == kEmptyWord);
+                if constexpr (SPLIT) ok = ok && arr.hi[r] <= a.eps_ord;  // (filter_results of the epsilon condition)
                 base += (uint32_t)__builtin_popcountll(ballot(ok));
                 return ok ? idx : kEmptyWord;
             }
@@ -1076,29 +1314,38 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
     const size_t epilogue_bytes = (size_t)64 * R * 12;
     size_t lds_small = (size_t)4 << a.hbits;
     if (lds_small < epilogue_bytes) lds_small = epilogue_bytes;
-    if constexpr (R >= 8 && !FILT) {
+    // FAR of a filtered launch (hnsw_search_kernel, SPLIT): 256 keys, twice as many with each step of filt_level (the host:
+    // what it knows of the filter's selectivity, and launches at this ef that reported overflows)
+    const size_t far_bytes = FILT ? (size_t)2048 << (a.filt_level < kFiltLevels ? a.filt_level : kFiltLevels - 1u) : 0;
+    if constexpr (R >= 8 || FILT) {
         // Searches that visit far more than a 16 KB LDS table holds: the whole visited set in HBM, one table per resident
         // wave.  From ef 317 on only: below, the LDS table with a spill table behind it is as fast or faster now that a
         // launch cannot run out of spill tables (20 M x 128, 10 000 queries, LDS + spill against this: ef 200 6.4 / 7.0 ms,
         // ef 300 9.5 / 9.6, ef 400 14.2 / 12.3, ef 508 23.2 / 15.7; double hashing then took another 10 % off the
-        // left-hand numbers).
-        if (a.hbits >= 13 && a.ghash) {
+        // left-hand numbers).  Filtered searches at any ef once launches reported that the 8 KB table is outgrown: a
+        // filter that keeps a tenth makes a search visit ten times the nodes, and a 16-32 KB table beside the candidate
+        // buffer leaves 3-6 queries per CU.
+        if (a.ghash && a.hbits >= (FILT ? 12u : 13u)) {
             // persistent blocks: as many as are resident at once, each with its own table
-            static const uint32_t resident = [&] {
+            const size_t pers_lds = epilogue_bytes > far_bytes ? epilogue_bytes : far_bytes;
+            const uint32_t resident = [&] {
                 int per_cu = 0, dev = 0;
                 hipDeviceProp_t prop;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hnsw_search_kernel<NCH, GPB, R, 1, true, FILT>, 64,
-                                                                 epilogue_bytes) != hipSuccess ||
+                                                                 pers_lds) != hipSuccess ||
                     hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu <= 0)
                     return 2048u;
                 return (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
             }();
             uint32_t blocks = resident < kGlobalHashBlocks ? resident : kGlobalHashBlocks;
             if (a.nq < blocks) blocks = a.nq;
+            SearchArgs c = a;
+            c.stage_off = 0;  // (the candidate buffer shares the epilogue's space: it is done with when the epilogue starts)
+            c.cb_cap = (uint32_t)(far_bytes / 8);
             if (a.g.metric == 0)
-                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 1, true, FILT>), dim3(blocks), dim3(64), epilogue_bytes, stream, a);
+                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 1, true, FILT>), dim3(blocks), dim3(64), pers_lds, stream, c);
             else
-                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 1, false, FILT>), dim3(blocks), dim3(64), epilogue_bytes, stream, a);
+                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 1, false, FILT>), dim3(blocks), dim3(64), pers_lds, stream, c);
             lds_small = 0;
         }
     }
@@ -1126,7 +1373,14 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
         if (a.spill && lds_small > (size_t)16 * 1024) lds_small = (size_t)16 * 1024;
         if (lds_small > (size_t)64 * 1024) lds_small = (size_t)64 * 1024;
         // (behind the table: the 64 R keys of KeyArray::merge)
-        const size_t stage_bytes = FILT ? 0 : (size_t)64 * R * 8;
+        // (behind the table: the 64 R keys of KeyArray::merge; filtered: the buffer of the candidates that are not allowed)
+        size_t stage_bytes = (size_t)64 * R * 8;
+        if constexpr (FILT) {
+            stage_bytes = far_bytes;
+            if (lds_small < ((size_t)4 << a.hbits) + stage_bytes) lds_small = ((size_t)4 << a.hbits) + stage_bytes;
+            if (lds_small > (size_t)64 * 1024) lds_small = (size_t)64 * 1024;
+            b.cb_cap = (uint32_t)(stage_bytes / 8);
+        }
         b.lds_entries = (uint32_t)((lds_small - stage_bytes) / 4);
         b.stage_off = b.lds_entries;
         auto is_prime = [](uint32_t v) {  // (a few trial divisions below 16 384)
@@ -1178,15 +1432,18 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
 template <int NCH, int GPB>
 int launch_r(const SearchArgs& a, hipStream_t stream, std::string* err) {
     if (a.allow) {
-        // filtered: the array also holds the live candidates that are not results (about
-        // ef / selectivity keys in all) - twice the registers of the bare search, and 1024 keys in
-        // the large configuration
-        // (the caller raises filt_level when launches at this ef report key-array overflows: a filter that keeps half
-        // the elements at ef 64 holds 128 live keys, one that keeps a tenth at ef 32 holds 320)
-        const uint32_t level = (a.ef <= 64 ? 0u : a.ef <= 128 ? 1u : 2u) + a.filt_level;
-        if (level == 0) return launch_cfg<NCH, GPB, 2, 16, true>(a, stream, err);
-        if (level == 1) return launch_cfg<NCH, GPB, 4, 16, true>(a, stream, err);
-        return launch_cfg<NCH, GPB, 8, 16, true>(a, stream, err);
+        // filtered: the first level's key array holds the allowed nodes only, so it is sized like the bare search's; the
+        // candidates that are not allowed wait in a buffer in LDS (hnsw_search_kernel, SPLIT; its size: launch_cfg).  The
+        // large configuration behind it is the one-array design with 1024 keys.
+        // (half the rows in flight per scoring pass, as the bare search has from three key registers on: a filtered
+        // hop brings 2-12 unvisited neighbours, and the registers that frees make four waves per SIMD)
+        constexpr int GF = GPB >= 2 ? GPB / 2 : GPB;
+        if (a.ef <= 60) return launch_cfg<NCH, GF, 1, 16, true>(a, stream, err);
+        if (a.ef <= 124) return launch_cfg<NCH, GF, 2, 16, true>(a, stream, err);
+        if (a.ef <= 188) return launch_cfg<NCH, GF, 3, 16, true>(a, stream, err);
+        if (a.ef <= 252) return launch_cfg<NCH, GF, 4, 16, true>(a, stream, err);
+        if (a.ef <= 316) return launch_cfg<NCH, GF, 5, 16, true>(a, stream, err);
+        return launch_cfg<NCH, GF, 8, 16, true>(a, stream, err);
     }
     // capacity 64 R > ef: with capacity == ef every tie at the bound that is pushed off the end sends
     // its query to the large configuration (measured on the C4 data: ef 64 took 13.4 ms against 7.4 ms

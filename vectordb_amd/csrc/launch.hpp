@@ -22,6 +22,7 @@ constexpr uint32_t kSpillBits = 14;        // 16 384 entries (64 KB) per spill t
 constexpr uint32_t kSpillTablesMin = 512;  // spill tables per launch: nq within [512, 4096] (32-256 MB).  A table goes back when its
 constexpr uint32_t kSpillTablesMax = 4096; // query ends, and a GPU holds at most 4096 of these searches at once (16 per CU by
                                            // their LDS): with nq >= 4096 a query always finds one
+constexpr uint32_t kFiltLevels = 5;        // filtered searches: the first level's candidate buffer in LDS holds 256 << level keys
 constexpr uint32_t kRedoKeyOverflow = 4;   // header word: first-level queries whose KEY ARRAY overflowed (filtered searches)
 constexpr uint32_t kRedoSpillMap = 8;      // word offset in the work list's header of the bitmap of spill tables in use
 constexpr uint32_t kRedoHeader = kRedoSpillMap + kSpillTablesMax / 32;  // words ahead of the re-run list
@@ -52,7 +53,7 @@ struct HnswSearchWork {
     uint32_t* ghash = nullptr;    // nullable: [kGlobalHashBlocks << kGlobalHashBits] u32, visited tables in HBM (large ef)
     uint32_t* report = nullptr;   // nullable, host-mapped [4]: {queries that outgrew the LDS visited table, nq, queries whose key
                                   // array overflowed at the first level, unused} of this launch
-    uint32_t filt_level = 0;      // filtered searches: key registers of the first level = 2, 4, 8 by ef, this many steps up
+    uint32_t filt_level = 0;      // filtered searches: the first level's candidate buffer holds 256 << filt_level keys (< kFiltLevels)
     uint32_t hbits_bias = 0;      // added to log2 of the visited-set size the launcher picks
     uint32_t* redo = nullptr;     // [kRedoHeader + nq] u32; the header ([0] re-run count, [1] unanswerable filtered queries,
                                   // [2] spill tables taken, [3] queries beyond heap_cap, [kRedoKeyOverflow], [kRedoSpillMap..]
