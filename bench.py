@@ -501,7 +501,7 @@ def run_hnsw(args, dd, rank, local_rank, world, dev, cores, threads):
     # command (counters cannot be read from inside the process); the committed summary is quoted
     # when the workload is the one it was collected on.
     traffic, traffic_src = None, None
-    for rel in ("profiles/r2/hnsw_c2_pmc_fetch.json", "profiles/r1/hnsw_c2_pmc_fetch_final.json"):
+    for rel in ("profiles/r3/hnsw_c2_pmc_fetch.json", "profiles/r2/hnsw_c2_pmc_fetch.json", "profiles/r1/hnsw_c2_pmc_fetch_final.json"):
         pmc = os.path.join(ROOT, rel)
         if os.path.exists(pmc) and args.build == "host" and (n, dim, args.nq, k, args.M, chosen) == (1_000_000, 128, 10_000, 10, 16, 32):
             with open(pmc) as f:
