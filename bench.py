@@ -788,8 +788,14 @@ def run_bruteforce(args, dev, cores, threads, standalone: bool):
 
     def roof(name, ms, tf):
         peak = MFMA_PEAK_TF["fp32" if name == "fp32" else "bf16"]
+        extra = {}
+        if name != "fp32" and (n, dim, nq, k) == (1_000_000, 960, 10_000, 10):
+            # what this step runs at with the MFMAs alone (no operand stream, no fragment reads, no epilogue) at the clock
+            # the chip holds under the load: measured once, profiles/r3/bf16_gemm_four_wave_experiment.txt (12.15 ms)
+            extra = {"peak_sustained": 1580.0, "frac_of_peak_sustained": round(tf / 1580.0, 4),
+                     "peak_sustained_source": "profiles/r3/bf16_gemm_four_wave_experiment.txt (the same step with MFMAs only)"}
         return {"ms_per_batch": round(ms, 3), "queries_per_s": round(nq / ms * 1e3, 1),
-                "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), **extra,
                              "traffic": None, "kernel": "bf_gemm_filter (f32)" if name == "fp32" else "bf_gemm8_filter (bf16)",
                              "kernel_ms": round(ms, 3),
                              "kernel_ms_note": "HIP events around the whole step on its stream: prepare-queries, the slab launches of "
