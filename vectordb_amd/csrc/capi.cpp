@@ -939,7 +939,9 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
     tr.lap("device rounds (layer 0)", dev_ids.size());
     {
         uint32_t found = 0, fixed = 0;
-        if (build_repair_orphans(links0, (uint32_t)total, g0.l0stride, maxM0, stream, &found, &fixed, &err) != 0) throw DeviceError(err);
+        if (!std::getenv("VDB_BUILD_NO_REPAIR") &&  // (experiments)
+            build_repair_orphans(links0, (uint32_t)total, g0.l0stride, maxM0, stream, &found, &fixed, &err) != 0)
+            throw DeviceError(err);
         if (tr.on) std::fprintf(stderr, "[vdb build] elements without an inbound link on layer 0: %u, given one: %u\n", found, fixed);
         tr.lap("orphan repair", found);
     }

@@ -41,11 +41,58 @@
 #include "launch.hpp"
 #include "traversal_common.hpp"
 
+// Compiled in four parts (Makefile: -DVDB_PART=0..3, one object each, in parallel - as one translation unit the
+// instantiations take seven minutes): part 0 = bare searches of rows up to 128 floats + the entry point, 1 = bare, longer
+// rows, 2 / 3 = the same two for filtered searches.  Without VDB_PART the file is one translation unit.
+#ifndef VDB_PART
+#define VDB_PART (-1)
+#endif
+
 namespace vdb {
+
+namespace detail {
+using namespace dev;
+struct SearchArgs {
+    DevGraph g;
+    const float* queries;  // [nq][dim]
+    uint32_t nq, k, ef, hbits;
+    uint32_t lds_entries;  // LdsVisited::size of this launch
+    uint32_t lds_mod;      // LdsVisited::mod
+    uint32_t stage_off;    // word offset in the block's LDS of the 64 R keys that KeyArray::merge stages (behind the LDS
+                           // table; 0 in the configurations without one, where it shares the epilogue's space)
+    float* out_dist;       // [nq][k]
+    uint64_t* out_label;   // [nq][k]
+    uint32_t* out_stats;   // nullable [nq][4]
+    const uint32_t* allow; // filtered search: bit i of word i/32 = node i may enter the results
+    uint32_t* redo;        // [0] = count, [1] = queries that could not be answered, [2] = spill tables taken,
+                           // [kRedoHeader + i] = query ids to re-run
+    uint32_t* spill;       // nullable: [spill_tables << kSpillBits], see LdsVisited
+    uint32_t spill_tables;
+    uint32_t* ghash;       // global-hash configuration: [gridDim.x][1 << kGlobalHashBits]
+    uint32_t* bitmaps;     // large configuration: [gridDim.x][bitmap_words]
+    uint32_t* report;      // nullable, host-mapped: [0] = queries the fast configuration gave up on, [1] = nq
+    uint32_t bitmap_words;
+    uint32_t large_blocks; // grid of the large configuration (host side only)
+    uint32_t cb_cap;       // first-level filtered launches: keys the candidate buffer holds (at stage_off; see SPLIT)
+    uint32_t eps_ord;      // FILT only: the epsilon stop condition (HnswSearchWork), kEmptyWord = none
+    uint32_t eps_min;
+    uint32_t* fail_list;   // nullable: queries the large configuration could not answer, for hnsw_search_unbounded_kernel
+    uint32_t filt_level;   // host side only: see HnswSearchWork
+    uint64_t* heaps;       // [heap_blocks][heap_cap]
+    uint32_t heap_cap, heap_blocks;
+};
+
+// one part's dispatch over row length and ef (the parts it does not hold answer 5)
+int launch_search_part0(const SearchArgs& a, uint32_t nch, hipStream_t stream, std::string* err);
+int launch_search_part1(const SearchArgs& a, uint32_t nch, hipStream_t stream, std::string* err);
+int launch_search_part2(const SearchArgs& a, uint32_t nch, hipStream_t stream, std::string* err);
+int launch_search_part3(const SearchArgs& a, uint32_t nch, hipStream_t stream, std::string* err);
+}  // namespace detail
 
 namespace {
 
 using namespace dev;
+using detail::SearchArgs;
 
 // ------------------------------------------------------------------ visited set
 
@@ -360,35 +407,6 @@ struct KeyArray {
 
 // ------------------------------------------------------------------ the search
 
-struct SearchArgs {
-    DevGraph g;
-    const float* queries;  // [nq][dim]
-    uint32_t nq, k, ef, hbits;
-    uint32_t lds_entries;  // LdsVisited::size of this launch
-    uint32_t lds_mod;      // LdsVisited::mod
-    uint32_t stage_off;    // word offset in the block's LDS of the 64 R keys that KeyArray::merge stages (behind the LDS
-                           // table; 0 in the configurations without one, where it shares the epilogue's space)
-    float* out_dist;       // [nq][k]
-    uint64_t* out_label;   // [nq][k]
-    uint32_t* out_stats;   // nullable [nq][4]
-    const uint32_t* allow; // filtered search: bit i of word i/32 = node i may enter the results
-    uint32_t* redo;        // [0] = count, [1] = queries that could not be answered, [2] = spill tables taken,
-                           // [kRedoHeader + i] = query ids to re-run
-    uint32_t* spill;       // nullable: [spill_tables << kSpillBits], see LdsVisited
-    uint32_t spill_tables;
-    uint32_t* ghash;       // global-hash configuration: [gridDim.x][1 << kGlobalHashBits]
-    uint32_t* bitmaps;     // large configuration: [gridDim.x][bitmap_words]
-    uint32_t* report;      // nullable, host-mapped: [0] = queries the fast configuration gave up on, [1] = nq
-    uint32_t bitmap_words;
-    uint32_t large_blocks; // grid of the large configuration (host side only)
-    uint32_t cb_cap;       // first-level filtered launches: keys the candidate buffer holds (at stage_off; see SPLIT)
-    uint32_t eps_ord;      // FILT only: the epsilon stop condition (HnswSearchWork), kEmptyWord = none
-    uint32_t eps_min;
-    uint32_t* fail_list;   // nullable: queries the large configuration could not answer, for hnsw_search_unbounded_kernel
-    uint32_t filt_level;   // host side only: see HnswSearchWork
-    uint64_t* heaps;       // [heap_blocks][heap_cap]
-    uint32_t heap_cap, heap_blocks;
-};
 
 // FILT = the non-bare searchBaseLayerST (hnsw_core.hpp:1141-1148 with deleted elements or a filter):
 // every admitted node is a candidate, only allowed ones are results (:340-343), the search stops when
@@ -537,7 +555,7 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
         // only: the candidate taken is always the exact minimum by (distance, id).
         uint64_t* far = reinterpret_cast<uint64_t*>(lds + a.stage_off);
         uint32_t nr_hi = kEmptyWord, nr_lo = kEmptyWord;
-        uint32_t far_n = 0, tx = kEmptyWord, tx_step = 1u << 18;
+        uint32_t far_n = 0, near_n = 0, tx = kEmptyWord, tx_step = 1u << 18;  // (near_n: keys in NEAR)
         auto lds_sync = [&]() {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
@@ -558,6 +576,7 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
                 nr_hi = gh;
                 nr_lo = gl;
             }
+            near_n += take;
         };
         // One pass over FAR: keys below `ntx` go to NEAR while it has free lanes, dead keys (beyond the bound of a full
         // result set) go away, the others move up.  Leaves tx = the exclusive lower bound of what stayed.
@@ -595,6 +614,7 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
                 lds_sync();
                 far_n += 64;
                 nr_hi = nr_lo = kEmptyWord;
+                near_n = 0;
             }
             // FAR's smallest key by (distance, id) goes over first, whatever else does: after a refill the minimum of NEAR
             // is the minimum of both parts (ties in distance included)
@@ -619,6 +639,7 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
                 nr_hi = m;
                 nr_lo = ml;
             }
+            near_n += 1;
             const uint32_t want = m + 1u + tx_step;
             const uint32_t moved = far_sweep(want > m ? want : kEmptyWord);  // (no wrap-around)
             // the window follows what it caught: a quarter to three quarters of NEAR is what a sweep should bring
@@ -628,6 +649,11 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
         };
         // the minimum of NEAR: (distance, id, lane); distance all ones = NEAR is empty
         auto near_min = [&](uint32_t& mh, uint32_t& ml, int& ml_lane) {
+            if (near_n == 0) {  // (an index with a few deleted elements mostly has no such candidate: nothing to reduce)
+                mh = ml = kEmptyWord;
+                ml_lane = 63;
+                return;
+            }
             mh = wave_min_u32(nr_hi);
             ml = wave_min_u32(nr_hi == mh ? nr_lo : kEmptyWord);
             ml_lane = __builtin_ctzll(ballot(nr_hi == mh && nr_lo == ml) | (1ull << 63));
@@ -640,6 +666,7 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
                     nr_hi = cur_d;
                     nr_lo = cur;
                 }
+                near_n = 1;
                 bound = kEmptyWord;
             } else {
                 if (lane == 0) {
@@ -700,6 +727,7 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
                 if (from_cb) {
                     cand = nml;
                     if (lane == nm_lane) nr_hi = nr_lo = kEmptyWord;
+                    near_n -= 1;
                 } else {
                     (void)arr.pop_candidate(lane, cand);
                 }
@@ -1413,6 +1441,7 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
                                (size_t)64 * RL * 12, stream, a);
         e = hipGetLastError();
     }
+    if constexpr (FILT) {  // (the launcher hands the heaps to filtered searches only)
     if (e == hipSuccess && a.fail_list && a.heaps && a.heap_blocks) {
         uint32_t blocks = a.heap_blocks < a.large_blocks ? a.heap_blocks : a.large_blocks;
         if (a.nq < blocks) blocks = a.nq;
@@ -1422,6 +1451,7 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
             hipLaunchKernelGGL((hnsw_search_unbounded_kernel<NCH, GPB, false>), dim3(blocks), dim3(64), 0, stream, a);
         e = hipGetLastError();
     }
+    }
     if (e != hipSuccess) {
         if (err) *err = std::string("hnsw_search launch failed: ") + hipGetErrorString(e);
         return 3;
@@ -1429,9 +1459,9 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
     return 0;
 }
 
-template <int NCH, int GPB>
+template <int NCH, int GPB, bool FILT>
 int launch_r(const SearchArgs& a, hipStream_t stream, std::string* err) {
-    if (a.allow) {
+    if constexpr (FILT) {
         // filtered: the first level's key array holds the allowed nodes only, so it is sized like the bare search's; the
         // candidates that are not allowed wait in a buffer in LDS (hnsw_search_kernel, SPLIT; its size: launch_cfg).  The
         // large configuration behind it is the one-array design with 1024 keys.
@@ -1444,7 +1474,7 @@ int launch_r(const SearchArgs& a, hipStream_t stream, std::string* err) {
         if (a.ef <= 252) return launch_cfg<NCH, GF, 4, 16, true>(a, stream, err);
         if (a.ef <= 316) return launch_cfg<NCH, GF, 5, 16, true>(a, stream, err);
         return launch_cfg<NCH, GF, 8, 16, true>(a, stream, err);
-    }
+    } else {
     // capacity 64 R > ef: with capacity == ef every tie at the bound that is pushed off the end sends
     // its query to the large configuration (measured on the C4 data: ef 64 took 13.4 ms against 7.4 ms
     // at ef 62 and at ef 65)
@@ -1458,10 +1488,48 @@ int launch_r(const SearchArgs& a, hipStream_t stream, std::string* err) {
     if (a.ef <= 252) return launch_cfg<NCH, GH, 4, 8, false>(a, stream, err);
     if (a.ef <= 316) return launch_cfg<NCH, GH, 5, 10, false>(a, stream, err);
     return launch_cfg<NCH, GH, 8, 16, false>(a, stream, err);
+    }
+}
+
+// this part's share of the dispatch (SHORT: rows up to 128 floats)
+template <bool FILT, bool SHORT>
+int launch_part(const SearchArgs& a, uint32_t nch, hipStream_t stream, std::string* err) {
+#ifdef VDB_ONLY_DIM128  // (make FAST=1: a quick build for kernel experiments on 65-128-dimensional data; never shipped)
+    if (nch != 2 || !SHORT) {
+        if (err) *err = "this is a FAST=1 build: dim 65-128 only";
+        return 4;
+    }
+    return launch_r<2, 8, FILT>(a, stream, err);
+#else
+    if constexpr (SHORT) {
+        if (nch <= 1) return launch_r<1, 8, FILT>(a, stream, err);
+        return launch_r<2, 8, FILT>(a, stream, err);
+    } else {
+        if (nch <= 4) return launch_r<4, 4, FILT>(a, stream, err);
+        if (nch <= 8) return launch_r<8, 2, FILT>(a, stream, err);
+        return launch_r<16, 1, FILT>(a, stream, err);
+    }
+#endif
 }
 
 }  // namespace
 
+namespace detail {
+#if VDB_PART == 0 || VDB_PART == -1
+int launch_search_part0(const SearchArgs& a, uint32_t nch, hipStream_t stream, std::string* err) { return launch_part<false, true>(a, nch, stream, err); }
+#endif
+#if VDB_PART == 1 || VDB_PART == -1
+int launch_search_part1(const SearchArgs& a, uint32_t nch, hipStream_t stream, std::string* err) { return launch_part<false, false>(a, nch, stream, err); }
+#endif
+#if VDB_PART == 2 || VDB_PART == -1
+int launch_search_part2(const SearchArgs& a, uint32_t nch, hipStream_t stream, std::string* err) { return launch_part<true, true>(a, nch, stream, err); }
+#endif
+#if VDB_PART == 3 || VDB_PART == -1
+int launch_search_part3(const SearchArgs& a, uint32_t nch, hipStream_t stream, std::string* err) { return launch_part<true, false>(a, nch, stream, err); }
+#endif
+}  // namespace detail
+
+#if VDB_PART == 0 || VDB_PART == -1
 int launch_and_bitmaps(const uint32_t* a, const uint32_t* b, uint32_t* out, uint32_t words, hipStream_t stream) {
     if (words == 0) return 0;
     hipLaunchKernelGGL(and_bitmaps_kernel, dim3((words + 255) / 256), dim3(256), 0, stream, a, b, out, words);
@@ -1534,16 +1602,9 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
         return 3;
     }
     const uint32_t nch = (g.vstride + 63u) / 64u;
-#ifdef VDB_ONLY_DIM128  // (make FAST=1: a quick build for kernel experiments on 65-128-dimensional data; never shipped)
-    if (nch != 2) return unsupported("this is a FAST=1 build: dim 65-128 only");
-    return launch_r<2, 8>(a, stream, err);
-#else
-    if (nch <= 1) return launch_r<1, 8>(a, stream, err);
-    if (nch <= 2) return launch_r<2, 8>(a, stream, err);
-    if (nch <= 4) return launch_r<4, 4>(a, stream, err);
-    if (nch <= 8) return launch_r<8, 2>(a, stream, err);
-    return launch_r<16, 1>(a, stream, err);
-#endif
+    if (d_allow) return nch <= 2 ? detail::launch_search_part2(a, nch, stream, err) : detail::launch_search_part3(a, nch, stream, err);
+    return nch <= 2 ? detail::launch_search_part0(a, nch, stream, err) : detail::launch_search_part1(a, nch, stream, err);
 }
+#endif  // VDB_PART == 0 || VDB_PART == -1
 
 }  // namespace vdb
