@@ -14,7 +14,9 @@ def recall(h, x, q, metric):
     h.setefSearch(64)
     _, l = h.search_batch(q, 10)
     return datasets.recall_at_k(l, truth)
-for n, dim, M, efc, metric in ((2000, 128, 4, 40, vi.L2), (2000, 96, 4, 100, vi.IP), (9000, 128, 4, 40, vi.L2), (2000, 32, 6, 40, vi.L2)):
+shapes = ((2000, 128, 4, 40, vi.L2), (2000, 96, 4, 100, vi.IP), (9000, 128, 4, 40, vi.L2), (2000, 32, 6, 40, vi.L2))
+if os.environ.get('EXP_BIG'): shapes = ((80000, 96, 4, 100, vi.L2), (30000, 128, 4, 40, vi.L2), (80000, 32, 6, 100, vi.IP))
+for n, dim, M, efc, metric in shapes:
     defs, orph = [], []
     for s in range(seeds):
         x = datasets.clustered(n, dim, 5000 + s, normalize=(metric == vi.IP)); q = datasets.clustered(300, dim, 6000 + s, normalize=(metric == vi.IP))
