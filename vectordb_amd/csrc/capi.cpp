@@ -162,6 +162,7 @@ struct vdb_index {
     DevBuf vecs, links0, upper_row, upper_links, labels;
     DevBuf live;  // bit i = element i is not deleted; allocated only when the upload saw deleted elements
     std::map<uint32_t, uint32_t> hbits_bias;  // per ef: extra log2 of the visited-set size (guarded by scratch_lock)
+    std::map<uint32_t, uint32_t> vis_mean;    // per ef: nodes a bare search visits on average, as the launches reported (same lock)
     std::set<uint32_t> spill_ef;              // the ef values at which a launch had queries outgrow the LDS table (same lock)
     std::map<uint32_t, uint32_t> filt_level;  // per ef, filtered searches: doublings of the first level's candidate buffer (same lock)
     int spill_mode = spill_mode_from_env();   // -1 adaptive, 0 never, 1 always (read once, at creation)
@@ -560,6 +561,8 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
                 if (redone != 0) idx->spill_ef.insert(s.report_ef);
                 uint32_t& b = idx->hbits_bias[s.report_ef];
                 b = next_hbits_bias(b, redone, of);
+                if (!s.report_filtered && s.report[3] != 0)  // (latest launch: the figure moves with the data the index holds)
+                    idx->vis_mean[s.report_ef] = (uint32_t)std::min<uint64_t>((uint64_t)s.report[3] * 16u / of, 0x7FFFFFFFu);
                 // filtered searches: the first level keeps the candidates that are not allowed in a buffer in LDS (about
                 // ef (1 - s) / s live keys at selectivity s, plus the ones the shrinking bound has left behind); when more
                 // than 0.2 % of a launch outgrew it the next filtered launches at this ef get twice the buffer (sticky;
@@ -572,7 +575,7 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
                     lv = std::min(std::max(lv, s.report_level) + 1u, kFiltLevels - 1u);
                 }
             }
-            s.report[0] = s.report[1] = s.report[2] = 0;
+            s.report[0] = s.report[1] = s.report[2] = s.report[3] = 0;
             s.report_pending = false;
         } else {
             (void)hipGetLastError();  // hipErrorNotReady is not an error here
@@ -599,6 +602,8 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
     {
         auto it = idx->hbits_bias.find((uint32_t)ef);
         work.hbits_bias = it == idx->hbits_bias.end() ? 0u : it->second;
+        auto iv = idx->vis_mean.find((uint32_t)ef);
+        work.vis_mean = (iv == idx->vis_mean.end() || allow) ? 0u : iv->second;
     }
     // visited sets in HBM: bare searches at large ef, filtered ones once launches at this ef reported the LDS table outgrown
     if ((ef > 124 && !allow) || (allow && work.hbits_bias >= 1)) {
@@ -657,8 +662,8 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
     if (rc != 0) return set_error(rc, err);
     static const bool trace = std::getenv("VDB_TRACE_SEARCH") != nullptr;
     if (trace)
-        std::fprintf(stderr, "[vdb search] nq %zu ef %zu k %zu %s: visited-set bias %u, spill tables %s, candidate-buffer level %u, report %s\n",
-                     nq, ef, k, allow ? "filtered" : "bare", work.hbits_bias, work.spill ? "on" : "off", work.filt_level,
+        std::fprintf(stderr, "[vdb search] nq %zu ef %zu k %zu %s: visited-set bias %u (a search visits %u nodes), spill tables %s, candidate-buffer level %u, report %s\n",
+                     nq, ef, k, allow ? "filtered" : "bare", work.hbits_bias, work.vis_mean, work.spill ? "on" : "off", work.filt_level,
                      arm_report ? "armed" : "not armed");
     if (arm_report) {
         s.report_ef = (uint32_t)ef;
@@ -869,7 +874,7 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
     }
     if (sc->report_pending) {  // a query launch's observation still in flight: let it land, then drop it
         VDB_HIP(hipEventSynchronize(sc->report_done));
-        sc->report[0] = sc->report[1] = 0;
+        sc->report[0] = sc->report[1] = sc->report[3] = 0;
         sc->report_pending = false;
     }
     sc->report_ef = 0;  // (not an observation of a query launch)
@@ -893,8 +898,9 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
                         work.spill_tables = sc->spill_tables;
                     }
                     work.hbits_bias = next_hbits_bias(work.hbits_bias, redone, of);
+                    if (sc->report[3] != 0) work.vis_mean = (uint32_t)std::min<uint64_t>((uint64_t)sc->report[3] * 16u / of, 0x7FFFFFFFu);
                 }
-                sc->report[0] = sc->report[1] = 0;
+                sc->report[0] = sc->report[1] = sc->report[3] = 0;
                 sc->report_pending = false;
             } else {
                 (void)hipGetLastError();
@@ -934,7 +940,7 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
         }
     }
     VDB_HIP(hipStreamSynchronize(stream));
-    sc->report[0] = sc->report[1] = 0;
+    sc->report[0] = sc->report[1] = sc->report[3] = 0;
     sc->report_pending = false;
     tr.lap("device rounds (layer 0)", dev_ids.size());
     {
@@ -1291,6 +1297,8 @@ int vdb_search_batch_device_noalloc(const vdb_index* cidx, const float* d_querie
             std::unique_lock<std::mutex> lock(idx->scratch_lock);
             auto it = idx->hbits_bias.find((uint32_t)ef);
             work.hbits_bias = it == idx->hbits_bias.end() ? 0u : it->second;
+            auto iv = idx->vis_mean.find((uint32_t)ef);
+            work.vis_mean = (iv == idx->vis_mean.end() || idx->live.p) ? 0u : iv->second;
         }
         rc = launch_hnsw_search(idx->graph, d_queries, (uint32_t)nq, (uint32_t)k, (uint32_t)ef, (const uint32_t*)idx->live.p,
                                 d_out_dist, d_out_label, d_out_stats, work, (hipStream_t)stream_, &err);

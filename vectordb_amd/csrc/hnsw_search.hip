@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <type_traits>
 
@@ -78,6 +79,7 @@ struct SearchArgs {
     uint32_t eps_min;
     uint32_t* fail_list;   // nullable: queries the large configuration could not answer, for hnsw_search_unbounded_kernel
     uint32_t filt_level;   // host side only: see HnswSearchWork
+    uint32_t vis_mean;     // HnswSearchWork::vis_mean
     uint64_t* heaps;       // [heap_blocks][heap_cap]
     uint32_t heap_cap, heap_blocks;
 };
@@ -465,6 +467,7 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
             a.report[0] = n_work + spilled;  // the queries that outgrew the LDS table, whichever way they went on
             a.report[1] = a.nq;
             a.report[2] = a.redo[kRedoKeyOverflow];
+            a.report[3] = a.redo[kRedoVisitedSum];
         }
     }
 #pragma unroll 1
@@ -976,6 +979,9 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
             if (overflow) break;
         }
         if constexpr (VIS == 3) vis.release_spill(a.spill, a.redo + kRedoSpillMap, lane);
+        if constexpr (!LARGE) {  // what a search at this ef visits: the host sizes later launches' LDS tables by it (launch_cfg)
+            if (a.report && lane == 0) atomicAdd(&a.redo[kRedoVisitedSum], (nvis + 8u) >> 4);
+        }
 
         if (overflow) {
             if constexpr (!LARGE) {
@@ -1337,7 +1343,9 @@ __global__ __launch_bounds__(256) void and_bitmaps_kernel(const uint32_t* a, con
 
 // ------------------------------------------------------------------ launch
 
-template <int NCH, int GPB, int R, int RL, bool FILT>
+// GPBL: row chunks in flight in the large configuration's kernel; SPILL_ONLY: only ever called with spill tables
+// (the instantiations without them are left out)
+template <int NCH, int GPB, int R, int RL, bool FILT, int GPBL = GPB, bool SPILL_ONLY = false>
 int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
     const size_t epilogue_bytes = (size_t)64 * R * 12;
     size_t lds_small = (size_t)4 << a.hbits;
@@ -1387,7 +1395,7 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
         // query where C2 visits 900: sending most of a batch through the spill tables cost 5.9 ms against 2.6).
         static const uint32_t per_cu = [&] {  // blocks of this instantiation a CU holds by registers alone
             int n = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hnsw_search_kernel<NCH, GPB, R, 0, true, FILT>, 64, 1024) != hipSuccess || n <= 0)
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hnsw_search_kernel<NCH, GPB, R, SPILL_ONLY ? 3 : 0, true, FILT>, 64, 1024) != hipSuccess || n <= 0)
                 return 8u;
             // (a body under 100 registers could have 20: measured in round 3, profiles/r3/residency_and_batch_size.txt -
             // no gain at ef <= 100, where a loaded GPU runs at the HBM rate, and the 6 KB table that is left is outgrown
@@ -1396,9 +1404,23 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
         }();
         size_t share = ((size_t)160 * 1024 / per_cu) / 1024 * 1024;
         if (lds_small < share) lds_small = share;
-        // with spill tables to carry on in, never more than 16 KB (10 queries per CU): 32 KB for everyone cost more than
-        // the spilling of the long searches did (3.1 against 2.2 ms at ef 100 on the 20 M-row graph)
-        if (a.spill && lds_small > (size_t)16 * 1024) lds_small = (size_t)16 * 1024;
+        // with spill tables to carry on in, never the 32 KB that `hbits` may ask for: that cost more than the spilling of
+        // the long searches did (3.1 against 2.2 ms at ef 100 on the 20 M-row graph; round 2 capped at 16 KB, 10 per CU).
+        // Round 3, on the same graph at ef 100-300: 20 KB (8 per CU) is never slower than 16 KB (10 per CU) - these launches
+        // wait for rows whatever the residency - and the table that just holds an average search is the fastest one: a
+        // search that has spilled pays an L2 round trip per hop, so the later it spills the better, until the residency
+        // falls to 6 per CU (ms at 16 / 20 / 22 / 26 KB - ef 160, 2 840 nodes visited: 3.35 / 3.11 / 3.33 / 3.65; ef 200,
+        // 3 330 nodes: 5.49 / 4.36 / 4.35 / 4.97; ef 252, 3 910 nodes: 6.54 / 6.23 / 5.65 / 6.04; ef 300, 4 400 nodes: 8.56 /
+        // 8.21 / 8.47 / 8.23).  So: 20 KB, and 22 KB when that is the table whose fill limit reaches the average that the
+        // earlier launches at this ef reported (vis_mean) where 20 KB's does not.
+        if (FILT && a.spill && lds_small > (size_t)16 * 1024) lds_small = (size_t)16 * 1024;  // (filtered: the candidate buffer is added below)
+        if (!FILT && a.spill && lds_small > (size_t)16 * 1024) {
+            auto holds = [&](size_t kb) {
+                const size_t entries = (kb * 1024 - (size_t)64 * R * 8) / 4, limit = entries - (entries >> 2);
+                return limit * 100 >= (size_t)a.vis_mean * 97;
+            };
+            lds_small = (a.vis_mean != 0 && !holds(20) && holds(22) ? (size_t)22 : (size_t)20) * 1024;
+        }
         if (lds_small > (size_t)64 * 1024) lds_small = (size_t)64 * 1024;
         // (behind the table: the 64 R keys of KeyArray::merge)
         // (behind the table: the 64 R keys of KeyArray::merge; filtered: the buffer of the candidates that are not allowed)
@@ -1425,19 +1447,21 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
                 hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 3, true, FILT>), dim3(a.nq), dim3(64), lds_small, stream, b);
             else
                 hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 3, false, FILT>), dim3(a.nq), dim3(64), lds_small, stream, b);
-        } else if (a.g.metric == 0)
-            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 0, true, FILT>), dim3(a.nq), dim3(64), lds_small, stream, b);
-        else
-            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 0, false, FILT>), dim3(a.nq), dim3(64), lds_small, stream, b);
+        } else if constexpr (!SPILL_ONLY) {
+            if (a.g.metric == 0)
+                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 0, true, FILT>), dim3(a.nq), dim3(64), lds_small, stream, b);
+            else
+                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 0, false, FILT>), dim3(a.nq), dim3(64), lds_small, stream, b);
+        }
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) {
         const uint32_t blocks = a.nq < a.large_blocks ? a.nq : a.large_blocks;
         if (a.g.metric == 0)
-            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, RL, 2, true, FILT>), dim3(blocks), dim3(64),
+            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPBL, RL, 2, true, FILT>), dim3(blocks), dim3(64),
                                (size_t)64 * RL * 12, stream, a);
         else
-            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, RL, 2, false, FILT>), dim3(blocks), dim3(64),
+            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPBL, RL, 2, false, FILT>), dim3(blocks), dim3(64),
                                (size_t)64 * RL * 12, stream, a);
         e = hipGetLastError();
     }
@@ -1484,6 +1508,15 @@ int launch_r(const SearchArgs& a, hipStream_t stream, std::string* err) {
     // neighbours, not 16-32, and the 32 registers that frees take the body from 134-150 to 92-127: four waves per SIMD
     // instead of three (C2, 100 000 queries: ef 128 10.8 -> 8.5 ms, ef 200 15.9 -> 12.6, ef 252 19.6 -> 14.9).
     constexpr int GH = GPB >= 2 ? GPB / 2 : GPB;
+    // ... unless the launch carries spill tables AND a table of 16 KB or more, i.e. earlier launches at this ef outgrew
+    // the smaller ones: that is a large graph (a hop there brings 16-20 unvisited neighbours: two passes of 16), and its
+    // tables bound the residency at 7-10 queries per CU whatever the registers (20 M x 128: ef 128 2.89 -> 2.69 ms, ef 160
+    // 3.58 -> 3.35, ef 252 6.78 -> 6.54, ef 300 8.96 -> 8.56; 145-155 registers)
+    if (GH != GPB && a.spill && a.hbits >= 12u) {
+        if (a.ef <= 188) return launch_cfg<NCH, GPB, 3, 6, false, GH, true>(a, stream, err);
+        if (a.ef <= 252) return launch_cfg<NCH, GPB, 4, 8, false, GH, true>(a, stream, err);
+        if (a.ef <= 316) return launch_cfg<NCH, GPB, 5, 10, false, GH, true>(a, stream, err);
+    }
     if (a.ef <= 188) return launch_cfg<NCH, GH, 3, 6, false>(a, stream, err);
     if (a.ef <= 252) return launch_cfg<NCH, GH, 4, 8, false>(a, stream, err);
     if (a.ef <= 316) return launch_cfg<NCH, GH, 5, 10, false>(a, stream, err);
@@ -1583,6 +1616,7 @@ int launch_hnsw_search(const DevGraph& g, const float* d_queries, uint32_t nq, u
     a.bitmap_words = work.bitmap_words;
     a.large_blocks = work.large_blocks ? work.large_blocks : 1u;
     a.filt_level = work.filt_level;
+    a.vis_mean = work.vis_mean;
     a.ghash = work.ghash;
     a.report = work.report;
     a.eps_ord = work.eps_ord;

@@ -24,6 +24,7 @@ constexpr uint32_t kSpillTablesMax = 4096; // query ends, and a GPU holds at mos
                                            // their LDS): with nq >= 4096 a query always finds one
 constexpr uint32_t kFiltLevels = 5;        // filtered searches: the first level's candidate buffer in LDS holds 256 << level keys
 constexpr uint32_t kRedoKeyOverflow = 4;   // header word: first-level queries whose KEY ARRAY overflowed (filtered searches)
+constexpr uint32_t kRedoVisitedSum = 5;    // header word: sum over the first-level queries of (visited nodes + 8) / 16, launches with a report
 constexpr uint32_t kRedoSpillMap = 8;      // word offset in the work list's header of the bitmap of spill tables in use
 constexpr uint32_t kRedoHeader = kRedoSpillMap + kSpillTablesMax / 32;  // words ahead of the re-run list
 
@@ -52,11 +53,13 @@ inline uint32_t next_hbits_bias(uint32_t bias, uint32_t outgrew, uint32_t nq) {
 struct HnswSearchWork {
     uint32_t* ghash = nullptr;    // nullable: [kGlobalHashBlocks << kGlobalHashBits] u32, visited tables in HBM (large ef)
     uint32_t* report = nullptr;   // nullable, host-mapped [4]: {queries that outgrew the LDS visited table, nq, queries whose key
-                                  // array overflowed at the first level, unused} of this launch
+                                  // array overflowed at the first level, sum of the queries' visited nodes / 16} of this launch
     uint32_t filt_level = 0;      // filtered searches: the first level's candidate buffer holds 256 << filt_level keys (< kFiltLevels)
     uint32_t hbits_bias = 0;      // added to log2 of the visited-set size the launcher picks
+    uint32_t vis_mean = 0;        // nodes a search at this ef visits on average, from earlier launches' reports (0 = not known):
+                                  // sizes the LDS table of the launches that have spill tables behind it (launch_cfg)
     uint32_t* redo = nullptr;     // [kRedoHeader + nq] u32; the header ([0] re-run count, [1] unanswerable filtered queries,
-                                  // [2] spill tables taken, [3] queries beyond heap_cap, [kRedoKeyOverflow], [kRedoSpillMap..]
+                                  // [2] spill tables taken, [3] queries beyond heap_cap, [kRedoKeyOverflow], [kRedoVisitedSum], [kRedoSpillMap..]
                                   // spill tables in use) is zeroed by the launcher
     uint32_t spill_tables = 0;    // a multiple of 32, at most kSpillTablesMax
     uint32_t* spill = nullptr;    // nullable: [spill_tables << kSpillBits] u32, second-level visited tables in HBM for the
