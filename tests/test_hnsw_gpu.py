@@ -105,6 +105,24 @@ def test_visited_overflow_is_exact(orc, monkeypatch, nq, spill):
         assert_same_results((dist, label), o.search(q, 100), st)
 
 
+@pytest.mark.parametrize("dim,ef", [(100, 200), (40, 300), (200, 160)])
+def test_table_size_and_rows_in_flight_follow_the_reports(orc, monkeypatch, dim, ef):
+    """Round 3: launches with spill tables behind a table of 16 KB or more take the kernels with twice the rows in flight
+    at ef > 124, and from the third launch on a 20 / 22 KB table chosen from the reported average of visited nodes
+    (launch_cfg).  Five launches walk through those configurations; every one equals the oracle."""
+    monkeypatch.delenv("VDB_SPILL", raising=False)
+    x = datasets.uniform(7000, dim, 41)
+    q = datasets.uniform(200, dim, 42)
+    h, o = build_pair(orc, x, vi.L2, 16, 64)
+    h.to_device(0)
+    h.setefSearch(ef)
+    o.set_ef(ef)
+    ref = o.search(q, 100)
+    for _ in range(5):
+        dist, label, st = h.search_batch(q, 100, stats=True)
+        assert_same_results((dist, label), ref, st)
+
+
 def test_spill_pool_grows_with_the_batch(orc, monkeypatch):
     """The pool holds one spill table per query of the largest batch (512 to 4096) and a table goes back
     to it when its query ends: a 20 000-query batch after a small one re-allocates the pool, and its
