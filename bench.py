@@ -40,6 +40,11 @@ sys.path.insert(0, ROOT)
 
 EF_SWEEP = (32, 64, 96, 128, 192, 256)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+# What a kernel that does nothing but this path's row gathers gets (tools/micro/gather_ceiling.hip, measured on the box:
+# profiles/r3/pipelined_walk_experiment.txt): random 512-B rows, one dependent gather per step, 8-16 waves per CU
+GATHER_PEAK_GBS_1M = 7600.0     # 1 M rows (0.5 GB: partly in the 256 MB Infinity Cache)
+GATHER_PEAK_GBS_LARGE = 6200.0  # 20 M - 100 M rows (10 - 51 GB)
+GATHER_PEAK_SOURCE = "profiles/r3/pipelined_walk_experiment.txt (tools/micro/gather_ceiling.hip: the row gathers alone)"
 MFMA_PEAK_TF = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense peaks, TFLOP/s
 
 
@@ -540,7 +545,10 @@ def run_hnsw(args, dd, rank, local_rank, world, dev, cores, threads):
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_source": traffic_src, "kernel": "hnsw_search_kernel", "kernel_ms": round(kern_ms, 4),
-                     "algorithmic_bytes_per_launch": alg_bytes},
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "peak_gather": GATHER_PEAK_GBS_1M if n <= 2_000_000 else GATHER_PEAK_GBS_LARGE,
+                     "frac_of_peak_gather": round(achieved / (GATHER_PEAK_GBS_1M if n <= 2_000_000 else GATHER_PEAK_GBS_LARGE), 4),
+                     "peak_gather_source": GATHER_PEAK_SOURCE},
         "cpu_baseline": cpu,
     }
     if by_ef is not None:
@@ -699,7 +707,9 @@ def run_c5_shard_one_gpu(args, dev, threads):
         by_ef[str(ef)] = {"recall_at_100": round(rec, 4), "ms_per_batch": round(ms, 3), "queries_per_s": round(nq / ms * 1e3, 1),
                           "mean_ndis": round(float(stn[:, 0].mean()), 1), "mean_hops": round(float(stn[:, 1].mean()), 1),
                           "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg}}
+                                       "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg,
+                                       "peak_gather": GATHER_PEAK_GBS_LARGE, "frac_of_peak_gather": round(alg / ms / 1e6 / GATHER_PEAK_GBS_LARGE, 4),
+                                       "peak_gather_source": GATHER_PEAK_SOURCE}}
         if rec >= 0.95:
             chosen = ef
             break
