@@ -428,7 +428,8 @@ constexpr bool four_waves(int nch, int gpb, int r, int vis, bool filt) {
     return vis != 2 && nch <= 4 && (r <= 2 || (nch * gpb <= 8 && (nch <= 2 || r <= 5)));
 }
 
-template <int NCH, int GPB, int R, int VIS, bool IS_L2, bool FILT>
+// FULL: rows of exactly NCH chunks (score_nodes) - the bare kernels for 64- and 128-float rows are compiled both ways.
+template <int NCH, int GPB, int R, int VIS, bool IS_L2, bool FILT, bool FULL = false>
 __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) void hnsw_search_kernel(SearchArgs a) {
     // SPLIT (round 3): the first-level filtered launches keep two structures, as the reference keeps two heaps.  The key
     // array holds the ALLOWED nodes only - it is then exactly the bare search's array: results = entries 0..ef-1, bound =
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
 
         // ---- entry point and greedy descent, hnsw_core.hpp:1111-1138
         uint32_t cur = g.entry;
-        uint32_t cur_d = readlane(score_nodes<NCH, GPB, IS_L2>(g, q, cur, 1u, lane), 0);
+        uint32_t cur_d = readlane(score_nodes<NCH, GPB, IS_L2, FULL>(g, q, cur, 1u, lane), 0);
         ndis += 1;
         uint32_t cur_row = g.max_level > 0 ? g.upper_row[cur] : 0u;  // first upper list of `cur`
         for (int level = g.max_level; level > 0; --level) {
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
                 if (n == 0) break;
                 // all n distances are evaluated by the reference too; the scan keeps the
                 // first strict minimum below cur_d
-                uint32_t d = score_nodes<NCH, GPB, IS_L2>(g, q, nb, n, lane);
+                uint32_t d = score_nodes<NCH, GPB, IS_L2, FULL>(g, q, nb, n, lane);
                 if ((uint32_t)lane >= n) d = kEmptyWord;
                 const uint32_t bd = wave_min_u32(d);
                 if (bd < cur_d) {  // first lane holding the minimum == first strict improvement of the scan
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) voi
                 const uint32_t ids_part = c0 == 0 ? ids_c : bpermute(ids_c, (lane + 32) & 63);
                 uint32_t dis = 0;  // requested ahead of the row gathers, used after them
                 if constexpr (FILT) dis = (uint32_t)lane < m ? not_allowed(ids_part) : 0u;
-                uint32_t dord = score_nodes<NCH, GPB, IS_L2>(g, q, ids_part, m, lane);
+                uint32_t dord = score_nodes<NCH, GPB, IS_L2, FULL>(g, q, ids_part, m, lane);
                 if ((uint32_t)lane >= m) dord = kEmptyWord;
                 {
                     const uint32_t best = wave_min_u32(dord);
@@ -1345,7 +1346,7 @@ __global__ __launch_bounds__(256) void and_bitmaps_kernel(const uint32_t* a, con
 
 // GPBL: row chunks in flight in the large configuration's kernel; SPILL_ONLY: only ever called with spill tables
 // (the instantiations without them are left out)
-template <int NCH, int GPB, int R, int RL, bool FILT, int GPBL = GPB, bool SPILL_ONLY = false>
+template <int NCH, int GPB, int R, int RL, bool FILT, int GPBL = GPB, bool SPILL_ONLY = false, bool FULL = false>
 int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
     const size_t epilogue_bytes = (size_t)64 * R * 12;
     size_t lds_small = (size_t)4 << a.hbits;
@@ -1367,7 +1368,7 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
             const uint32_t resident = [&] {
                 int per_cu = 0, dev = 0;
                 hipDeviceProp_t prop;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hnsw_search_kernel<NCH, GPB, R, 1, true, FILT>, 64,
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hnsw_search_kernel<NCH, GPB, R, 1, true, FILT, FULL>, 64,
                                                                  pers_lds) != hipSuccess ||
                     hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu <= 0)
                     return 2048u;
@@ -1379,9 +1380,9 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
             c.stage_off = 0;  // (the candidate buffer shares the epilogue's space: it is done with when the epilogue starts)
             c.cb_cap = (uint32_t)(far_bytes / 8);
             if (a.g.metric == 0)
-                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 1, true, FILT>), dim3(blocks), dim3(64), pers_lds, stream, c);
+                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 1, true, FILT, FULL>), dim3(blocks), dim3(64), pers_lds, stream, c);
             else
-                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 1, false, FILT>), dim3(blocks), dim3(64), pers_lds, stream, c);
+                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 1, false, FILT, FULL>), dim3(blocks), dim3(64), pers_lds, stream, c);
             lds_small = 0;
         }
     }
@@ -1395,7 +1396,7 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
         // query where C2 visits 900: sending most of a batch through the spill tables cost 5.9 ms against 2.6).
         static const uint32_t per_cu = [&] {  // blocks of this instantiation a CU holds by registers alone
             int n = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hnsw_search_kernel<NCH, GPB, R, SPILL_ONLY ? 3 : 0, true, FILT>, 64, 1024) != hipSuccess || n <= 0)
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hnsw_search_kernel<NCH, GPB, R, SPILL_ONLY ? 3 : 0, true, FILT, FULL>, 64, 1024) != hipSuccess || n <= 0)
                 return 8u;
             // (a body under 100 registers could have 20: measured in round 3, profiles/r3/residency_and_batch_size.txt -
             // no gain at ef <= 100, where a loaded GPU runs at the HBM rate, and the 6 KB table that is left is outgrown
@@ -1444,24 +1445,24 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
         // hash probe): the caller passes the tables only when earlier launches at this ef needed them
         if (a.spill) {
             if (a.g.metric == 0)
-                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 3, true, FILT>), dim3(a.nq), dim3(64), lds_small, stream, b);
+                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 3, true, FILT, FULL>), dim3(a.nq), dim3(64), lds_small, stream, b);
             else
-                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 3, false, FILT>), dim3(a.nq), dim3(64), lds_small, stream, b);
+                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 3, false, FILT, FULL>), dim3(a.nq), dim3(64), lds_small, stream, b);
         } else if constexpr (!SPILL_ONLY) {
             if (a.g.metric == 0)
-                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 0, true, FILT>), dim3(a.nq), dim3(64), lds_small, stream, b);
+                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 0, true, FILT, FULL>), dim3(a.nq), dim3(64), lds_small, stream, b);
             else
-                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 0, false, FILT>), dim3(a.nq), dim3(64), lds_small, stream, b);
+                hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPB, R, 0, false, FILT, FULL>), dim3(a.nq), dim3(64), lds_small, stream, b);
         }
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) {
         const uint32_t blocks = a.nq < a.large_blocks ? a.nq : a.large_blocks;
         if (a.g.metric == 0)
-            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPBL, RL, 2, true, FILT>), dim3(blocks), dim3(64),
+            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPBL, RL, 2, true, FILT, FULL>), dim3(blocks), dim3(64),
                                (size_t)64 * RL * 12, stream, a);
         else
-            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPBL, RL, 2, false, FILT>), dim3(blocks), dim3(64),
+            hipLaunchKernelGGL((hnsw_search_kernel<NCH, GPBL, RL, 2, false, FILT, FULL>), dim3(blocks), dim3(64),
                                (size_t)64 * RL * 12, stream, a);
         e = hipGetLastError();
     }
@@ -1483,7 +1484,7 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
     return 0;
 }
 
-template <int NCH, int GPB, bool FILT>
+template <int NCH, int GPB, bool FILT, bool FULL = false>
 int launch_r(const SearchArgs& a, hipStream_t stream, std::string* err) {
     if constexpr (FILT) {
         // filtered: the first level's key array holds the allowed nodes only, so it is sized like the bare search's; the
@@ -1502,8 +1503,8 @@ int launch_r(const SearchArgs& a, hipStream_t stream, std::string* err) {
     // capacity 64 R > ef: with capacity == ef every tie at the bound that is pushed off the end sends
     // its query to the large configuration (measured on the C4 data: ef 64 took 13.4 ms against 7.4 ms
     // at ef 62 and at ef 65)
-    if (a.ef <= 60) return launch_cfg<NCH, GPB, 1, 2, false>(a, stream, err);
-    if (a.ef <= 124) return launch_cfg<NCH, GPB, 2, 4, false>(a, stream, err);
+    if (a.ef <= 60) return launch_cfg<NCH, GPB, 1, 2, false, GPB, false, FULL>(a, stream, err);
+    if (a.ef <= 124) return launch_cfg<NCH, GPB, 2, 4, false, GPB, false, FULL>(a, stream, err);
     // From three key registers on, half the rows in flight per pass of score_nodes: at these ef a hop brings 4-8 unvisited
     // neighbours, not 16-32, and the 32 registers that frees take the body from 134-150 to 92-127: four waves per SIMD
     // instead of three (C2, 100 000 queries: ef 128 10.8 -> 8.5 ms, ef 200 15.9 -> 12.6, ef 252 19.6 -> 14.9).
@@ -1513,14 +1514,14 @@ int launch_r(const SearchArgs& a, hipStream_t stream, std::string* err) {
     // tables bound the residency at 7-10 queries per CU whatever the registers (20 M x 128: ef 128 2.89 -> 2.69 ms, ef 160
     // 3.58 -> 3.35, ef 252 6.78 -> 6.54, ef 300 8.96 -> 8.56; 145-155 registers)
     if (GH != GPB && a.spill && a.hbits >= 12u) {
-        if (a.ef <= 188) return launch_cfg<NCH, GPB, 3, 6, false, GH, true>(a, stream, err);
-        if (a.ef <= 252) return launch_cfg<NCH, GPB, 4, 8, false, GH, true>(a, stream, err);
-        if (a.ef <= 316) return launch_cfg<NCH, GPB, 5, 10, false, GH, true>(a, stream, err);
+        if (a.ef <= 188) return launch_cfg<NCH, GPB, 3, 6, false, GH, true, FULL>(a, stream, err);
+        if (a.ef <= 252) return launch_cfg<NCH, GPB, 4, 8, false, GH, true, FULL>(a, stream, err);
+        if (a.ef <= 316) return launch_cfg<NCH, GPB, 5, 10, false, GH, true, FULL>(a, stream, err);
     }
-    if (a.ef <= 188) return launch_cfg<NCH, GH, 3, 6, false>(a, stream, err);
-    if (a.ef <= 252) return launch_cfg<NCH, GH, 4, 8, false>(a, stream, err);
-    if (a.ef <= 316) return launch_cfg<NCH, GH, 5, 10, false>(a, stream, err);
-    return launch_cfg<NCH, GH, 8, 16, false>(a, stream, err);
+    if (a.ef <= 188) return launch_cfg<NCH, GH, 3, 6, false, GH, false, FULL>(a, stream, err);
+    if (a.ef <= 252) return launch_cfg<NCH, GH, 4, 8, false, GH, false, FULL>(a, stream, err);
+    if (a.ef <= 316) return launch_cfg<NCH, GH, 5, 10, false, GH, false, FULL>(a, stream, err);
+    return launch_cfg<NCH, GH, 8, 16, false, GH, false, FULL>(a, stream, err);
     }
 }
 
@@ -1532,9 +1533,12 @@ int launch_part(const SearchArgs& a, uint32_t nch, hipStream_t stream, std::stri
         if (err) *err = "this is a FAST=1 build: dim 65-128 only";
         return 4;
     }
+    if (!FILT && a.g.vstride == 128u) return launch_r<2, 8, FILT, !FILT>(a, stream, err);
     return launch_r<2, 8, FILT>(a, stream, err);
 #else
     if constexpr (SHORT) {
+        // (bare searches over rows of exactly 64 or 128 floats: the kernels without the per-chunk tests)
+        if (!FILT && a.g.vstride == 64u * nch) return nch <= 1 ? launch_r<1, 8, FILT, !FILT>(a, stream, err) : launch_r<2, 8, FILT, !FILT>(a, stream, err);
         if (nch <= 1) return launch_r<1, 8, FILT>(a, stream, err);
         return launch_r<2, 8, FILT>(a, stream, err);
     } else {

@@ -100,6 +100,7 @@ __device__ __forceinline__ uint32_t group_distance(const f32x4 (&q)[NCH], const 
         }
     }
     // pairwise tree over the 64 virtual lanes: 2 levels in-lane, 4 across lanes
+    // (the compiler packs the lane arithmetic itself: v_pk_add_f32 with negation and v_pk_fma_f32, two elements per instruction)
     float s = (a0 + a1) + (a2 + a3);
     s = s + dpp_f32<kDppXor1>(s);
     s = s + dpp_f32<kDppXor2>(s);
@@ -109,7 +110,9 @@ __device__ __forceinline__ uint32_t group_distance(const f32x4 (&q)[NCH], const 
     return f2ord(s);
 }
 
-template <int NCH, int GPB, bool IS_L2>
+// FULL: the rows are exactly NCH chunks long (vstride == 64 NCH: 64, 128, 256, ... floats) - every lane loads every chunk and
+// the per-chunk tests of the general form (14 of its 25 instructions per group of four rows) are not compiled.
+template <int NCH, int GPB, bool IS_L2, bool FULL = false>
 __device__ __forceinline__ uint32_t score_nodes(const DevGraph& g, const f32x4 (&q)[NCH], uint32_t ids, uint32_t m,
                                                 int lane) {
     const int grp = lane >> 4, t = lane & 15;
@@ -124,6 +127,18 @@ __device__ __forceinline__ uint32_t score_nodes(const DevGraph& g, const f32x4 (
 #pragma unroll
         for (int b = 0; b < GPB; ++b) nid[b] = bpermute(ids, (int)((4u * (base + b) + (uint32_t)grp) & 63u));
         f32x4 x[GPB][NCH];
+        if constexpr (FULL) {
+#pragma unroll
+            for (int b = 0; b < GPB; ++b) {
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) asm volatile("" : "=v"(x[b][j]));  // (as below: rows beyond m may hold anything)
+                if (4u * (base + b) + (uint32_t)grp < m) {
+                    const float* row = g.vecs + (size_t)nid[b] * (64u * NCH) + 4 * t;
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j) x[b][j] = *reinterpret_cast<const f32x4*>(row + 64 * j);
+                }
+            }
+        } else {
 #pragma unroll
         for (int b = 0; b < GPB; ++b) {
             // Rows beyond m are never loaded and their lanes' results never used (every caller masks lanes >= m), so
@@ -142,6 +157,7 @@ __device__ __forceinline__ uint32_t score_nodes(const DevGraph& g, const f32x4 (
                 for (int j = 0; j < NCH; ++j)
                     if ((uint32_t)(64 * j + 4 * t) < vstride) x[b][j] = *reinterpret_cast<const f32x4*>(row + 64 * j);
             }
+        }
         }
         // Group b's result (the same in its 16 lanes) is kept by lane t == b of each group ...
         uint32_t keep = kEmptyWord;
