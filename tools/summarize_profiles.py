@@ -17,10 +17,10 @@ if have("c3prof/*/*kernel_stats.csv"):
 
 # FETCH_SIZE of the traversal at the headline configuration (ef = 32 -> the R = 1 instantiation)
 rows = [r for r in csv.DictReader(open(newest("c2pmc/*/*counter_collection.csv")))
-        if "hnsw_search_kernel<2, 8, 1, 0, true, false>" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"
+        if "hnsw_search_kernel<2, 8, 1, 0, true, false" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"
         and int(r["Grid_Size"]) == 10000 * 64]
 kb = sum(float(r["Counter_Value"]) for r in rows) / len(rows)
-json.dump({"kernel": "hnsw_search_kernel<2, 8, 1, 0, true, false> (NCH=2, GPB=8, R=1, VIS=0 = LDS hash, L2, bare)",
+json.dump({"kernel": rows[0]["Kernel_Name"].split("(vdb")[0].split("::")[-1] + " (NCH=2, GPB=8, R=1, VIS=0 = LDS hash, L2, bare, rows of exactly 128 floats)",
            "FETCH_SIZE_KB_mean": kb, "dispatches": len(rows), "traffic_bytes_per_launch": int(kb * 1024 * 2),
            "VGPR_Count": rows[0]["VGPR_Count"], "SGPR_Count": rows[0]["SGPR_Count"], "LDS_Block_Size": rows[0]["LDS_Block_Size"],
            "note": "traffic = FETCH_SIZE(KB)*1024*2: gfx950 reports half the bytes of 16-B-per-lane loads (MI355X_MICROARCH.md, HBM); "
