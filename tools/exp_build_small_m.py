@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Recall of the device build against the host build at small M on small sets, many data seeds (development tool):
 python tools/exp_build_small_m.py [seeds]   - prints the deficit distribution; VDB_BUILD_BATCH_DIV / VDB_BUILD_NO_REPAIR
-switch the builder's batch fraction and orphan pass."""
+switch the builder's batch fraction and orphan pass in a diagnostic build of the library (make DIAG=1)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -885,7 +885,9 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
     std::string err;
     size_t done = 0, round = 0;
     size_t batch_div = M < 8 ? 16 : 4;
+#ifdef VDB_DIAG  // (make DIAG=1: tools/exp_build_small_m.py; the shipped library reads no such switch)
     if (const char* e = std::getenv("VDB_BUILD_BATCH_DIV")) batch_div = (size_t)std::max(1l, std::atol(e));
+#endif
     while (done < dev_ids.size()) {
         // as in search_device: an observation is read only behind the event of the round that wrote it
         bool arm_report = true;
@@ -945,8 +947,11 @@ void device_rounds(vdb_index* idx, const std::vector<uint32_t>& dev_ids, size_t 
     tr.lap("device rounds (layer 0)", dev_ids.size());
     {
         uint32_t found = 0, fixed = 0;
-        if (!std::getenv("VDB_BUILD_NO_REPAIR") &&  // (experiments)
-            build_repair_orphans(links0, (uint32_t)total, g0.l0stride, maxM0, stream, &found, &fixed, &err) != 0)
+        bool repair = true;
+#ifdef VDB_DIAG  // (make DIAG=1: tools/exp_build_small_m.py)
+        repair = std::getenv("VDB_BUILD_NO_REPAIR") == nullptr;
+#endif
+        if (repair && build_repair_orphans(links0, (uint32_t)total, g0.l0stride, maxM0, stream, &found, &fixed, &err) != 0)
             throw DeviceError(err);
         if (tr.on) std::fprintf(stderr, "[vdb build] elements without an inbound link on layer 0: %u, given one: %u\n", found, fixed);
         tr.lap("orphan repair", found);
