@@ -356,6 +356,26 @@ def run_hnsw(args, dd, rank, local_rank, world, dev, cores, threads):
     if rank == 0:
         log(f"timed: {elapsed / args.steps * 1e3:.4f} ms per step, {qps:.4e} queries/s over {world} rank(s)")
 
+    # ---- the same K steps spread over two HIP streams (outside the timed region; not `value`): a launch ends in a tail - its
+    # last queries finish on a half-empty GPU - that the next batch's launch on the other stream fills
+    two_streams = None
+    if rank == 0 and world == 1:
+        sts2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        for i in range(4):
+            with torch.cuda.stream(sts2[i & 1]):
+                h.search_batch(dq, k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            with torch.cuda.stream(sts2[i & 1]):
+                h.search_batch(dq, k)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t0
+        two_streams = {"queries_per_s": round(args.nq * args.steps / el2, 1), "ms_per_step": round(el2 / args.steps * 1e3, 4),
+                       "algorithmic_GBps": round(alg_bytes * args.steps / el2 / 1e9, 1),
+                       "note": "independent batches on alternating streams; `value` above is one stream, one launch after the other"}
+        log(f"two streams: {two_streams['ms_per_step']} ms per step, {two_streams['queries_per_s']:.4e} queries/s")
+
     # ---- the same batch at larger ef (outside the timed region; not `value`): the traversal beyond the headline's ef is
     # where C4 at high recall and C5 live, so its rate belongs in the driver's record too
     by_ef = None
@@ -551,6 +571,8 @@ def run_hnsw(args, dd, rank, local_rank, world, dev, cores, threads):
                      "peak_gather_source": GATHER_PEAK_SOURCE},
         "cpu_baseline": cpu,
     }
+    if two_streams is not None:
+        out["headline_on_two_streams"] = two_streams
     if by_ef is not None:
         out["traversal_by_ef"] = by_ef
     if filtered is not None:
@@ -642,13 +664,48 @@ def run_c4_one_gpu(args, dev, threads):
     ms_merge = float(np.mean([b.elapsed_time(c) for _, b, c in ev]))
     ms = ms_search + ms_merge
     gbs = alg / ms_search / 1e6
+    # The same step with each shard's search on a HIP stream of its own (one GPU holding several shards: a launch's tail -
+    # the last queries, finishing on a half-empty GPU - overlaps the next shards' searches), joined by events before the merge.
+    streams = [torch.cuda.Stream(device=dev) for _ in shards]
+    main = torch.cuda.current_stream(dev)
+
+    def step_streams():
+        start = torch.cuda.Event()
+        start.record(main)
+        res = []
+        for h, st in zip(shards, streams):
+            st.wait_event(start)
+            with torch.cuda.stream(st):
+                res.append(h.search_batch(dq, k))
+            done = torch.cuda.Event()
+            done.record(st)
+            main.wait_event(done)
+        return vi.merge_topk(torch.stack([r[0] for r in res]), torch.stack([r[1] for r in res]))
+
+    _, ml_s = step_streams()
+    torch.cuda.synchronize()
+    same_streams = bool(torch.equal(ml_s, ml))
+    for _ in range(3):
+        step_streams()
+        torch.cuda.synchronize()
+    ev_s = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev_s:
+        a.record()
+        step_streams()
+        b.record()
+    torch.cuda.synchronize()
+    ms_streams = float(np.mean([a.elapsed_time(b) for a, b in ev_s]))
     log(f"c4: ef sweep {sweep} -> ef={ef}; {ms:.2f} ms per batch ({ms_search:.2f} search of {G} shards + {ms_merge:.2f} merge), "
         f"{gbs:.0f} GB/s algorithmic")
     return {"workload": f"BASELINE.json configs[3]: HNSW {n}x{dim} rows L2-normalised, metric 1 - <a,b>, {G} shards x {n // G} rows, "
                         f"M={M}, efConstruction=200, {nq}-query batch, k={k}; all {G} shards on ONE GPU, searched one after the other",
             "ef": ef, "ef_sweep_recall_at_10": sweep, "recall_at_10": sweep[ef], "ms_per_batch": round(ms, 3),
             "ms_split": {"search_all_shards": round(ms_search, 3), "merge_topk": round(ms_merge, 3)},
-            "queries_per_s_one_gpu": round(nq / ms * 1e3, 1), "shard_build_seconds_device": round(build_s, 1),
+            "queries_per_s_one_gpu": round(nq / ms * 1e3, 1),
+            "shards_on_streams_of_their_own": {"ms_per_batch": round(ms_streams, 3), "queries_per_s_one_gpu": round(nq / ms_streams * 1e3, 1),
+                                               "algorithmic_GBps_whole_step": round(alg / ms_streams / 1e6, 1),
+                                               "same_labels_as_the_sequential_step": same_streams},
+            "shard_build_seconds_device": round(build_s, 1),
             "shard_build_points_per_s": round(n / build_s, 0),
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                          "traffic": None, "kernel": f"hnsw_search_kernel ({G} launches per batch)", "kernel_ms": round(ms_search, 3),
