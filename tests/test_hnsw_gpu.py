@@ -123,6 +123,30 @@ def test_table_size_and_rows_in_flight_follow_the_reports(orc, monkeypatch, dim,
         assert_same_results((dist, label), ref, st)
 
 
+def test_batches_on_two_streams_in_turn(orc):
+    """a serving loop enqueues consecutive batches on two streams in turn (the next launch fills the last
+    one's tail).  Scratch is per (index, stream), the adaptive state per index: eight launches of two different batches
+    overlapping on one index, every one equal to the oracle."""
+    import torch
+    x = datasets.clustered(30000, 64, 51)
+    qs = [datasets.clustered(3000, 64, 52 + i) for i in range(2)]
+    h, o = build_pair(orc, x, vi.L2, 16, 100)
+    h.to_device(0)
+    h.setefSearch(150)
+    o.set_ef(150)
+    refs = [o.search(q, 10) for q in qs]
+    dq = [torch.from_numpy(q).cuda() for q in qs]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+    outs = []
+    for i in range(8):
+        with torch.cuda.stream(streams[i & 1]):
+            outs.append((i & 1, h.search_batch(dq[i & 1], 10, stats=True)))
+    torch.cuda.synchronize()
+    for which, (dist, label, st) in outs:
+        assert_same_results((dist.cpu().numpy(), label.cpu().numpy().view(np.uint64), ), refs[which], st.cpu().numpy().view(np.uint32))
+
+
 def test_spill_pool_grows_with_the_batch(orc, monkeypatch):
     """The pool holds one spill table per query of the largest batch (512 to 4096) and a table goes back
     to it when its query ends: a 20 000-query batch after a small one re-allocates the pool, and its
