@@ -1412,7 +1412,7 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
         // search that has spilled pays an L2 round trip per hop, so the later it spills the better, until the residency
         // falls to 6 per CU (ms at 16 / 20 / 22 / 26 KB - ef 160, 2 840 nodes visited: 3.35 / 3.11 / 3.33 / 3.65; ef 200,
         // 3 330 nodes: 5.49 / 4.36 / 4.35 / 4.97; ef 252, 3 910 nodes: 6.54 / 6.23 / 5.65 / 6.04; ef 300, 4 400 nodes: 8.56 /
-        // 8.21 / 8.47 / 8.23).  So: 20 KB, and 22 KB when that is the table whose fill limit reaches the average that the
+        // 8.21 / 8.47 / 8.23).  So: 20 KB, and 22 or 26 KB when that is the table whose fill limit reaches the average that the
         // earlier launches at this ef reported (vis_mean) where 20 KB's does not.
         if (FILT && a.spill && lds_small > (size_t)16 * 1024) lds_small = (size_t)16 * 1024;  // (filtered: the candidate buffer is added below)
         if (!FILT && a.spill && lds_small > (size_t)16 * 1024) {
@@ -1420,7 +1420,9 @@ int launch_cfg(const SearchArgs& a, hipStream_t stream, std::string* err) {
                 const size_t entries = (kb * 1024 - (size_t)64 * R * 8) / 4, limit = entries - (entries >> 2);
                 return limit * 100 >= (size_t)a.vis_mean * 97;
             };
-            lds_small = (a.vis_mean != 0 && !holds(20) && holds(22) ? (size_t)22 : (size_t)20) * 1024;
+            size_t kb = 20;
+            if (a.vis_mean != 0 && !holds(20)) kb = holds(22) ? 22 : holds(26) ? 26 : 20;  // (26 KB: 6 per CU, the last size that pays)
+            lds_small = kb * 1024;
         }
         if (lds_small > (size_t)64 * 1024) lds_small = (size_t)64 * 1024;
         // (behind the table: the 64 R keys of KeyArray::merge)
