@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -581,6 +582,30 @@ int search_device(vdb_index* idx, const float* d_queries, size_t nq, size_t k, c
             (void)hipGetLastError();  // hipErrorNotReady is not an error here
             arm_report = false;
         }
+    }
+    // A first bare launch at this ef: start from what the launches at the nearest ef values that have reported taught, not
+    // from the smallest table - on a large graph the first launches at a new ef otherwise send most of a batch through the
+    // spill tables or the large configuration.  The nodes a search visits grow like ef^x with x = 0.36 on C2 (1 M rows:
+    // 560 / 890 / 1 090 at ef 32 / 100 / 200) and 0.72 on 20 M rows (2 020 / 3 330 / 4 400 at ef 100 / 200 / 300): x comes
+    // from the two nearest ef that are known, or is taken low (0.35) when only one is - the table size only ever grows
+    // with the reports, so the starting point must not be beyond where they would settle.
+    if (!allow && idx->hbits_bias.find((uint32_t)ef) == idx->hbits_bias.end() && !idx->vis_mean.empty()) {
+        auto hi = idx->vis_mean.lower_bound((uint32_t)ef);
+        auto near = hi == idx->vis_mean.end() ? std::prev(hi) : hi;
+        if (hi != idx->vis_mean.begin() && hi != idx->vis_mean.end() && ef - std::prev(hi)->first < hi->first - ef) near = std::prev(hi);
+        double x = 0.35;
+        if (idx->vis_mean.size() >= 2) {
+            auto other = near == idx->vis_mean.begin() ? std::next(near) : std::prev(near);
+            if (near->second > 0 && other->second > 0)
+                x = std::log((double)near->second / (double)other->second) / std::log((double)near->first / (double)other->first);
+            x = std::min(0.8, std::max(0.3, x));
+        }
+        const double guess = (double)near->second * std::pow((double)ef / (double)near->first, x);
+        // (the tables' fill limits: the 10 KB share holds about 1 700 nodes, 16 KB about 2 800 - launch_cfg)
+        const uint32_t bias = guess > 2800.0 ? 2u : guess > 1700.0 ? 1u : 0u;
+        idx->hbits_bias[(uint32_t)ef] = bias;
+        idx->vis_mean[(uint32_t)ef] = (uint32_t)guess;
+        if (bias) idx->spill_ef.insert((uint32_t)ef);
     }
     HnswSearchWork work;
     work.redo = (uint32_t*)s.redo.p;
