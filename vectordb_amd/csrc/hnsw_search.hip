@@ -428,7 +428,7 @@ constexpr bool four_waves(int nch, int gpb, int r, int vis, bool filt) {
     return vis != 2 && nch <= 4 && (r <= 2 || (nch * gpb <= 8 && (nch <= 2 || r <= 5)));
 }
 
-// FULL: rows of exactly NCH chunks (score_nodes) - the bare kernels for 64- and 128-float rows are compiled both ways.
+// FULL: rows of exactly NCH chunks (score_nodes) - the kernels for 64- and 128-float rows are compiled both ways.
 template <int NCH, int GPB, int R, int VIS, bool IS_L2, bool FILT, bool FULL = false>
 __global__ __launch_bounds__(64, four_waves(NCH, GPB, R, VIS, FILT) ? 4 : 2) void hnsw_search_kernel(SearchArgs a) {
     // SPLIT (round 3): the first-level filtered launches keep two structures, as the reference keeps two heaps.  The key
@@ -1495,12 +1495,12 @@ int launch_r(const SearchArgs& a, hipStream_t stream, std::string* err) {
         // (half the rows in flight per scoring pass, as the bare search has from three key registers on: a filtered
         // hop brings 2-12 unvisited neighbours, and the registers that frees make four waves per SIMD)
         constexpr int GF = GPB >= 2 ? GPB / 2 : GPB;
-        if (a.ef <= 60) return launch_cfg<NCH, GF, 1, 16, true>(a, stream, err);
-        if (a.ef <= 124) return launch_cfg<NCH, GF, 2, 16, true>(a, stream, err);
-        if (a.ef <= 188) return launch_cfg<NCH, GF, 3, 16, true>(a, stream, err);
-        if (a.ef <= 252) return launch_cfg<NCH, GF, 4, 16, true>(a, stream, err);
-        if (a.ef <= 316) return launch_cfg<NCH, GF, 5, 16, true>(a, stream, err);
-        return launch_cfg<NCH, GF, 8, 16, true>(a, stream, err);
+        if (a.ef <= 60) return launch_cfg<NCH, GF, 1, 16, true, GF, false, FULL>(a, stream, err);
+        if (a.ef <= 124) return launch_cfg<NCH, GF, 2, 16, true, GF, false, FULL>(a, stream, err);
+        if (a.ef <= 188) return launch_cfg<NCH, GF, 3, 16, true, GF, false, FULL>(a, stream, err);
+        if (a.ef <= 252) return launch_cfg<NCH, GF, 4, 16, true, GF, false, FULL>(a, stream, err);
+        if (a.ef <= 316) return launch_cfg<NCH, GF, 5, 16, true, GF, false, FULL>(a, stream, err);
+        return launch_cfg<NCH, GF, 8, 16, true, GF, false, FULL>(a, stream, err);
     } else {
     // capacity 64 R > ef: with capacity == ef every tie at the bound that is pushed off the end sends
     // its query to the large configuration (measured on the C4 data: ef 64 took 13.4 ms against 7.4 ms
@@ -1535,12 +1535,12 @@ int launch_part(const SearchArgs& a, uint32_t nch, hipStream_t stream, std::stri
         if (err) *err = "this is a FAST=1 build: dim 65-128 only";
         return 4;
     }
-    if (!FILT && a.g.vstride == 128u) return launch_r<2, 8, FILT, !FILT>(a, stream, err);
+    if (a.g.vstride == 128u) return launch_r<2, 8, FILT, true>(a, stream, err);
     return launch_r<2, 8, FILT>(a, stream, err);
 #else
     if constexpr (SHORT) {
-        // (bare searches over rows of exactly 64 or 128 floats: the kernels without the per-chunk tests)
-        if (!FILT && a.g.vstride == 64u * nch) return nch <= 1 ? launch_r<1, 8, FILT, !FILT>(a, stream, err) : launch_r<2, 8, FILT, !FILT>(a, stream, err);
+        // (rows of exactly 64 or 128 floats: the kernels without the per-chunk tests)
+        if (a.g.vstride == 64u * nch) return nch <= 1 ? launch_r<1, 8, FILT, true>(a, stream, err) : launch_r<2, 8, FILT, true>(a, stream, err);
         if (nch <= 1) return launch_r<1, 8, FILT>(a, stream, err);
         return launch_r<2, 8, FILT>(a, stream, err);
     } else {
